@@ -1,0 +1,209 @@
+/*
+ * npw_hip.h -- C-ABI of libnpw_hip.so, the MI355X (gfx950 / CDNA4) tile-kernel
+ * library underneath numpywren_amd.
+ *
+ * The reference (Vaishaal/numpywren) has no FFI: its seam is the duck-typed
+ * Python kernel interface `compute(*ndarrays, **kwargs)` invoked by
+ * RemoteCall (reference numpywren/lambdapack.py:354-384) with the callables of
+ * numpywren/kernels.py.  Each entry point below states which reference
+ * callable (file:line) it replaces.  INTEGRATION.md shows the ctypes stub a
+ * reference maintainer would add to kernels.py to bind them.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  No torch / numpy types.
+ *   - every function returns int: 0 = NPW_OK, <0 = error; the message for the
+ *     calling thread is available from npw_last_error().
+ *   - matrices are ROW-MAJOR (C order, matches NumPy) with an explicit leading
+ *     dimension `ld*` counted in ELEMENTS (row stride).
+ *   - all device pointers must belong to the current device of the calling
+ *     thread (npw_set_device).  All kernels are asynchronous on `stream`
+ *     (npw_stream_t == hipStream_t; NULL = the null stream).
+ *   - the caller owns every buffer, including workspaces (sizes come from the
+ *     *_workspace_bytes queries).  Inputs are never modified unless an output
+ *     pointer aliases them, which every kernel explicitly allows or forbids.
+ *   - thread-safe: may be called concurrently from several host threads.
+ */
+#ifndef NPW_HIP_H
+#define NPW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NPW_OK 0
+#define NPW_ERR_HIP (-1)      /* a HIP runtime call failed                     */
+#define NPW_ERR_ARG (-2)      /* invalid argument                              */
+#define NPW_ERR_NOT_PD (-3)   /* potrf: matrix not positive definite           */
+#define NPW_ERR_UNSUPPORTED (-4)
+
+typedef void* npw_stream_t; /* hipStream_t */
+typedef void* npw_event_t;  /* hipEvent_t  */
+
+/* ---- library / device management ------------------------------------------ */
+int npw_version(void);
+/* thread-local message of the last failing call on this thread ("" if none) */
+const char* npw_last_error(void);
+int npw_device_count(int* count);
+int npw_set_device(int device);
+int npw_get_device(int* device);
+/* name: gcnArchName of the device (e.g. "gfx950:sramecc+:xnack-") */
+int npw_device_info(int device, char* name, size_t name_len, size_t* total_mem_bytes,
+                    int* compute_units, int* clock_khz);
+int npw_mem_info(size_t* free_bytes, size_t* total_bytes);
+
+/* ---- memory: the HBM tile store + pinned host staging ----------------------
+ * Replaces the S3 object GET/PUT of BigMatrix (reference numpywren/matrix.py:
+ * 497-533 __s3_key_to_byte_io__/__save_matrix_to_s3__): tiles live in HBM,
+ * spill/gather goes through pinned host memory with async copies.            */
+int npw_malloc(void** dptr, size_t bytes);
+int npw_free(void* dptr);
+int npw_host_alloc(void** hptr, size_t bytes); /* pinned */
+int npw_host_free(void* hptr);
+int npw_memcpy_h2d_async(void* dst, const void* src, size_t bytes, npw_stream_t stream);
+int npw_memcpy_d2h_async(void* dst, const void* src, size_t bytes, npw_stream_t stream);
+int npw_memcpy_d2d_async(void* dst, const void* src, size_t bytes, npw_stream_t stream);
+/* copy between devices of one node (xGMI peer copy) */
+int npw_memcpy_peer_async(void* dst, int dst_device, const void* src, int src_device, size_t bytes,
+                          npw_stream_t stream);
+int npw_memset_async(void* dst, int byte_value, size_t bytes, npw_stream_t stream);
+/* strided 2-D copies (rows x row_bytes) for scatter/gather of ragged tiles */
+int npw_memcpy2d_h2d_async(void* dst, size_t dpitch, const void* src, size_t spitch,
+                           size_t row_bytes, size_t rows, npw_stream_t stream);
+int npw_memcpy2d_d2h_async(void* dst, size_t dpitch, const void* src, size_t spitch,
+                           size_t row_bytes, size_t rows, npw_stream_t stream);
+int npw_memcpy2d_d2d_async(void* dst, size_t dpitch, const void* src, size_t spitch,
+                           size_t row_bytes, size_t rows, npw_stream_t stream);
+
+/* ---- streams / events: the local worker pool --------------------------------
+ * Replaces the pywren worker fan-out + asyncio read/compute/write pipeline
+ * (reference numpywren/job_runner.py:224-370).                                */
+int npw_stream_create(npw_stream_t* stream, int high_priority);
+int npw_stream_destroy(npw_stream_t stream);
+int npw_stream_synchronize(npw_stream_t stream);
+int npw_stream_query(npw_stream_t stream, int* done);
+int npw_device_synchronize(void);
+int npw_event_create(npw_event_t* event, int timing);
+int npw_event_destroy(npw_event_t event);
+int npw_event_record(npw_event_t event, npw_stream_t stream);
+int npw_event_synchronize(npw_event_t event);
+int npw_event_query(npw_event_t event, int* done);
+int npw_stream_wait_event(npw_stream_t stream, npw_event_t event);
+int npw_event_elapsed_ms(npw_event_t start, npw_event_t stop, float* ms);
+
+/* ---- tile kernels ------------------------------------------------------------ */
+
+/* D = alpha * op(A) * op(B) + beta * C      (fp64, MFMA v_mfma_f64_16x16x4_f64)
+ *   op(X) = X if trans == 'N', X^T if trans == 'T'.
+ *   op(A) is m x k, op(B) is k x n, C and D are m x n.  C may be NULL iff beta == 0.
+ *   D may alias C exactly (same pointer and ld); D must not overlap A or B.
+ *   skip_flag (device int32, may be NULL): when non-NULL and *skip_flag != 0 at kernel
+ *   run time the product is skipped, i.e. D = beta * C (used for the reference's
+ *   allclose(x, 0) short-circuits without a host round trip).
+ * Replaces kernels.gemm (reference numpywren/kernels.py:239-244: A.dot(B) with
+ * transpose_A / transpose_B kwargs).                                           */
+int npw_dgemm(char transA, char transB, int64_t m, int64_t n, int64_t k, double alpha,
+              const double* A, int64_t lda, const double* B, int64_t ldb, double beta,
+              const double* C, int64_t ldc, double* D, int64_t ldd, const int32_t* skip_flag,
+              npw_stream_t stream);
+/* fp32 flavour on v_mfma_f32_16x16x4_f32 (BASELINE config 5). */
+int npw_sgemm(char transA, char transB, int64_t m, int64_t n, int64_t k, float alpha,
+              const float* A, int64_t lda, const float* B, int64_t ldb, float beta, const float* C,
+              int64_t ldc, float* D, int64_t ldd, const int32_t* skip_flag, npw_stream_t stream);
+
+/* D = S - X * Y^T   (S,D: m x n; X: m x k; Y: n x k).  D may alias S.
+ * skip_x / skip_y: optional device flags (see npw_is_zero): if either is set D = S.
+ * Replaces kernels.syrk (reference numpywren/kernels.py:212-215) -- the Cholesky
+ * trailing update, the north-star kernel.                                      */
+int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t lds,
+                     const double* X, int64_t ldx, const double* Y, int64_t ldy, double* D,
+                     int64_t ldd, const int32_t* skip_x, const int32_t* skip_y,
+                     npw_stream_t stream);
+
+/* Solve X * L^T = B for X, L lower triangular n x n (non-unit), B and X m x n.
+ * Only the lower triangle of L is read.  X may alias B.
+ * workspace: npw_dtrsm_rltn_workspace_bytes(m, n) bytes of device memory.
+ * Replaces kernels.trsm (reference numpywren/kernels.py:254-257:
+ * scipy.linalg.blas.dtrsm(1.0, x.T, y, lower=False, side=1) with x = L).      */
+size_t npw_dtrsm_rltn_workspace_bytes(int64_t m, int64_t n);
+int npw_dtrsm_rltn(int64_t m, int64_t n, const double* L, int64_t ldl, const double* B,
+                   int64_t ldb, double* X, int64_t ldx, void* workspace, npw_stream_t stream);
+
+/* Cholesky factor of the n x n SPD matrix A (only its lower triangle is read):
+ * Lout = lower triangular L with A = L L^T, strictly-upper part of Lout set to 0.
+ * Lout may alias A.  info_dev: device int32, set to 0 on success or to the 1-based
+ * index of the first non-positive pivot (then Lout is unspecified), like LAPACK.
+ * Replaces kernels.chol (reference numpywren/kernels.py:225-226 np.linalg.cholesky).*/
+size_t npw_dpotrf_lower_workspace_bytes(int64_t n);
+int npw_dpotrf_lower(int64_t n, const double* A, int64_t lda, double* Lout, int64_t ldl,
+                     int32_t* info_dev, void* workspace, npw_stream_t stream);
+
+/* Householder QR with compact-WY T of the m x n matrix A (m >= n), LAPACK
+ * DGEQRT3 conventions (H_j = I - tau_j v_j v_j^T, beta = -sign(alpha)*norm):
+ *   V (m x n, ldv): unit-lower-trapezoidal Householder vectors (diag = 1, upper = 0)
+ *   T (n x n, ldt): upper triangular, Q = I - V T V^T      (strictly-lower = 0)
+ *   R (n x n, ldr): upper triangular factor                 (strictly-lower = 0)
+ * A is not modified.  Replaces kernels.qr_factor -> fast_qr (reference
+ * numpywren/kernels.py:86-105,127-130; f2py dgeqrt3 + post-processing).        */
+size_t npw_dgeqrt_workspace_bytes(int64_t m, int64_t n);
+int npw_dgeqrt(int64_t m, int64_t n, const double* A, int64_t lda, double* V, int64_t ldv,
+               double* T, int64_t ldt, double* R, int64_t ldr, void* workspace,
+               npw_stream_t stream);
+
+/* out = sum_i in[i]   (count operands of rows x cols each; fp64 accumulate/output).
+ * in_is_f32[i] != 0 marks a float32 operand (the reference's add_matrices always
+ * produces float64: np.zeros(args[0].shape) += a).  in pointers are HOST arrays of
+ * device pointers / lds.  out may alias any in[i] with the same ld.
+ * Replaces kernels.add_matrices (reference numpywren/kernels.py:16-20).        */
+int npw_add_n(int count, const void* const* in, const int64_t* ld_in, const int32_t* in_is_f32,
+              int64_t rows, int64_t cols, double* out, int64_t ld_out, npw_stream_t stream);
+
+/* A[i,i] += lambda for i < min(rows, cols).  Replaces the `lambdav` diagonal shift
+ * applied on every read of a diagonal tile (reference numpywren/matrix.py:307-309).*/
+int npw_add_diag(double* A, int64_t rows, int64_t cols, int64_t lda, double lambda,
+                 npw_stream_t stream);
+
+/* *flag_dev = 1 if all |A[i,j]| <= atol (np.allclose(A, 0) with the default
+ * atol = 1e-8; NaN/Inf => 0), else 0.  flag_dev: device int32.
+ * Replaces the np.allclose(x, 0) tests in kernels.syrk / kernels.trsm
+ * (reference numpywren/kernels.py:213,255) and RemoteWrite's sparse-write test
+ * (reference numpywren/lambdapack.py:311).                                     */
+int npw_is_zero(const double* A, int64_t rows, int64_t cols, int64_t lda, double atol,
+                int32_t* flag_dev, npw_stream_t stream);
+
+/* B = A^T (A rows x cols, B cols x rows).  No aliasing.  Replaces the per-tile
+ * `.T` of BigMatrixView (reference numpywren/matrix.py:646-647,658-659).      */
+int npw_dtranspose(int64_t rows, int64_t cols, const double* A, int64_t lda, double* B,
+                   int64_t ldb, npw_stream_t stream);
+
+/* keep the lower (uplo='L') or upper ('U') triangle incl. diagonal of the rows x cols
+ * matrix, zero the rest; unit_diag != 0 forces the diagonal to 1.  In place.   */
+int npw_dtri_keep(char uplo, int unit_diag, int64_t rows, int64_t cols, double* A, int64_t lda,
+                  npw_stream_t stream);
+
+/* dst[i,j] = (dst_type) src[i,j]; types: 0 = f64, 1 = f32 */
+int npw_convert(int64_t rows, int64_t cols, const void* src, int64_t lds, int src_type, void* dst,
+                int64_t ldd, int dst_type, npw_stream_t stream);
+
+/* Fill a rows x cols fp64 tile with the deterministic synthetic generators used by
+ * bench.py / the experiments (never on the parity path):
+ *   kind 0: A[i,j] = x[row0+i] * x[col0+j]  (+ lambda on the global diagonal), x a
+ *           device vector -- the reference generator X X^T + lambda I with X = N x 1
+ *           (reference experiments/cholesky_experiment.py:78-92).
+ *   kind 1: counter-based standard-normal-ish noise seeded by (seed,row0+i,col0+j). */
+int npw_fill_outer(double* A, int64_t rows, int64_t cols, int64_t lda, const double* x,
+                   int64_t row0, int64_t col0, double lambda, npw_stream_t stream);
+int npw_fill_random(double* A, int64_t rows, int64_t cols, int64_t lda, uint64_t seed,
+                    int64_t row0, int64_t col0, npw_stream_t stream);
+
+/* sum of squares of a rows x cols matrix into *out_dev (device double, overwritten):
+ * used by residual checks at full size.                                        */
+int npw_dsumsq(const double* A, int64_t rows, int64_t cols, int64_t lda, double* out_dev,
+               npw_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NPW_HIP_H */

@@ -1,0 +1,339 @@
+// elementwise.hip -- HBM-bound tile helpers: n-ary add, diagonal shift, zero test,
+// transpose, triangle masks, dtype conversion, synthetic fills, sum of squares.
+//
+// All of them stream each byte once with 16-byte accesses where the row alignment allows
+// it; the grid is capped at a few blocks per CU and strides over the rest (HBM roofline:
+// bytes_in + bytes_out at ~6.3 TB/s achievable).
+#include "npw_internal.h"
+
+namespace npw {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 256 * 8;
+
+inline int grid_for(int64_t work_items) {
+    int64_t b = ceil_div(work_items, kThreads);
+    if (b < 1) b = 1;
+    if (b > kMaxBlocks) b = kMaxBlocks;
+    return (int)b;
+}
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+// ---- add_n -------------------------------------------------------------------------------
+constexpr int kMaxAdd = 8;
+struct AddArgs {
+    const void* in[kMaxAdd];
+    int64_t ld[kMaxAdd];
+    int32_t is_f32[kMaxAdd];
+    int count;
+};
+
+__global__ void add_n_kernel(AddArgs a, int64_t rows, int64_t cols, double* out, int64_t ld_out,
+                             bool accumulate) {
+    const int64_t total = rows * cols;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / cols, c = idx - r * cols;
+        // the reference accumulates left to right into zeros: ((0 + a0) + a1) + ...
+        double s = accumulate ? out[r * ld_out + c] : 0.0;
+#pragma unroll
+        for (int i = 0; i < kMaxAdd; ++i) {
+            if (i < a.count) {
+                const int64_t off = r * a.ld[i] + c;
+                s += a.is_f32[i] ? (double)reinterpret_cast<const float*>(a.in[i])[off]
+                                 : reinterpret_cast<const double*>(a.in[i])[off];
+            }
+        }
+        out[r * ld_out + c] = s;
+    }
+}
+
+// vectorised flavour: all operands fp64, contiguous rows (ld == cols), cols even, 16B aligned
+__global__ void add_n_vec_kernel(AddArgs a, int64_t total2, d2_t* out, bool accumulate) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total2;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        d2_t s = accumulate ? out[idx] : d2_t{0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < kMaxAdd; ++i)
+            if (i < a.count) s += reinterpret_cast<const d2_t*>(a.in[i])[idx];
+        out[idx] = s;
+    }
+}
+
+__global__ void add_diag_kernel(double* A, int64_t n, int64_t lda, double lambda) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        A[i * lda + i] += lambda;
+}
+
+__global__ void init_flag_kernel(int32_t* flag, int32_t v) { *flag = v; }
+
+__global__ void is_zero_kernel(const double* A, int64_t rows, int64_t cols, int64_t lda, double atol,
+                               int32_t* flag) {
+    const int64_t total = rows * cols;
+    bool bad = false;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / cols, c = idx - r * cols;
+        const double v = A[r * lda + c];
+        // np.allclose(v, 0): |v - 0| <= atol + rtol*|0|, and non-finite values never match
+        if (!(fabs(v) <= atol)) bad = true;
+    }
+    if (__any(bad)) {
+        if ((threadIdx.x & 63) == 0) atomicAnd(flag, 0);
+    }
+}
+
+__global__ void transpose_kernel(int64_t rows, int64_t cols, const double* A, int64_t lda, double* B,
+                                 int64_t ldb) {
+    __shared__ double tile[32][33];
+    const int64_t tiles_c = (cols + 31) / 32, tiles_r = (rows + 31) / 32;
+    for (int64_t t = blockIdx.x; t < tiles_r * tiles_c; t += gridDim.x) {
+        const int64_t tr = t / tiles_c, tc = t - tr * tiles_c;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+        for (int j = ty; j < 32; j += 8) {
+            const int64_t r = tr * 32 + j, c = tc * 32 + tx;
+            if (r < rows && c < cols) tile[j][tx] = A[r * lda + c];
+        }
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8) {
+            const int64_t r = tc * 32 + j, c = tr * 32 + tx;  // B is cols x rows
+            if (r < cols && c < rows) B[r * ldb + c] = tile[tx][j];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void tri_keep_kernel(bool lower, bool unit, int64_t rows, int64_t cols, double* A,
+                                int64_t lda) {
+    const int64_t total = rows * cols;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / cols, c = idx - r * cols;
+        if (r == c) {
+            if (unit) A[r * lda + c] = 1.0;
+        } else if (lower ? (c > r) : (c < r)) {
+            A[r * lda + c] = 0.0;
+        }
+    }
+}
+
+template <typename S, typename D>
+__global__ void convert_kernel(int64_t rows, int64_t cols, const S* src, int64_t lds, D* dst,
+                               int64_t ldd) {
+    const int64_t total = rows * cols;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / cols, c = idx - r * cols;
+        dst[r * ldd + c] = (D)src[r * lds + c];
+    }
+}
+
+__global__ void fill_outer_kernel(double* A, int64_t rows, int64_t cols, int64_t lda, const double* x,
+                                  int64_t row0, int64_t col0, double lambda) {
+    const int64_t total = rows * cols;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / cols, c = idx - r * cols;
+        double v = x[row0 + r] * x[col0 + c];
+        if (row0 + r == col0 + c) v += lambda;
+        A[r * lda + c] = v;
+    }
+}
+
+__device__ inline uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// counter-based N(0,1) samples (Box-Muller on two splitmix64 draws): value depends only on
+// (seed, global row, global col), so any tiling of the same matrix gives the same numbers.
+__global__ void fill_random_kernel(double* A, int64_t rows, int64_t cols, int64_t lda, uint64_t seed,
+                                   int64_t row0, int64_t col0) {
+    const int64_t total = rows * cols;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / cols, c = idx - r * cols;
+        const uint64_t key = splitmix64(seed ^ splitmix64((uint64_t)(row0 + r) * 0x100000001B3ULL + (uint64_t)(col0 + c)));
+        const uint64_t k2 = splitmix64(key);
+        const double u1 = ((double)(key >> 11) + 1.0) * (1.0 / 9007199254740993.0);
+        const double u2 = (double)(k2 >> 11) * (1.0 / 9007199254740992.0);
+        A[r * lda + c] = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+    }
+}
+
+__global__ void sumsq_kernel(const double* A, int64_t rows, int64_t cols, int64_t lda, double* out) {
+    const int64_t total = rows * cols;
+    double s = 0;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / cols, c = idx - r * cols;
+        const double v = A[r * lda + c];
+        s += v * v;
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    __shared__ double part[kThreads / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int i = 0; i < kThreads / 64; ++i) t += part[i];
+        atomicAdd(out, t);
+    }
+}
+
+}  // namespace
+}  // namespace npw
+
+using namespace npw;
+
+extern "C" {
+
+int npw_add_n(int count, const void* const* in, const int64_t* ld_in, const int32_t* in_is_f32,
+              int64_t rows, int64_t cols, double* out, int64_t ld_out, npw_stream_t stream) {
+    NPW_REQUIRE(count >= 0 && rows >= 0 && cols >= 0, "npw_add_n: bad sizes");
+    NPW_REQUIRE(out != nullptr || rows * cols == 0, "npw_add_n: out is NULL");
+    if (rows == 0 || cols == 0) return NPW_OK;
+    hipStream_t s = as_stream(stream);
+    if (count == 0) {
+        NPW_HIP_CHECK(hipMemset2DAsync(out, ld_out * 8, 0, cols * 8, rows, s));
+        return NPW_OK;
+    }
+    // operands are consumed kMaxAdd at a time, left to right; later passes accumulate into out
+    for (int base = 0; base < count; base += kMaxAdd) {
+        AddArgs a;
+        a.count = (count - base < kMaxAdd) ? count - base : kMaxAdd;
+        bool vec = (ld_out == cols) && (cols % 2 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+        for (int i = 0; i < kMaxAdd; ++i) {
+            if (i < a.count) {
+                a.in[i] = in[base + i];
+                a.ld[i] = ld_in[base + i];
+                a.is_f32[i] = in_is_f32 ? in_is_f32[base + i] : 0;
+                NPW_REQUIRE(a.in[i] != nullptr, "npw_add_n: operand %d is NULL", base + i);
+                vec = vec && !a.is_f32[i] && a.ld[i] == cols &&
+                      ((reinterpret_cast<uintptr_t>(a.in[i]) & 15) == 0);
+            } else {
+                a.in[i] = nullptr;
+                a.ld[i] = 0;
+                a.is_f32[i] = 0;
+            }
+        }
+        if (vec) {
+            const int64_t total2 = rows * cols / 2;
+            hipLaunchKernelGGL(add_n_vec_kernel, dim3(grid_for(total2)), dim3(kThreads), 0, s, a, total2,
+                               reinterpret_cast<d2_t*>(out), base > 0);
+        } else {
+            hipLaunchKernelGGL(add_n_kernel, dim3(grid_for(rows * cols)), dim3(kThreads), 0, s, a, rows,
+                               cols, out, ld_out, base > 0);
+        }
+        NPW_LAUNCH_CHECK();
+    }
+    return NPW_OK;
+}
+
+int npw_add_diag(double* A, int64_t rows, int64_t cols, int64_t lda, double lambda,
+                 npw_stream_t stream) {
+    const int64_t n = rows < cols ? rows : cols;
+    if (n <= 0) return NPW_OK;
+    NPW_REQUIRE(A != nullptr && lda >= cols, "npw_add_diag: bad arguments");
+    hipLaunchKernelGGL(add_diag_kernel, dim3(grid_for(n)), dim3(kThreads), 0, as_stream(stream), A, n,
+                       lda, lambda);
+    NPW_LAUNCH_CHECK();
+    return NPW_OK;
+}
+
+int npw_is_zero(const double* A, int64_t rows, int64_t cols, int64_t lda, double atol,
+                int32_t* flag_dev, npw_stream_t stream) {
+    NPW_REQUIRE(flag_dev != nullptr, "npw_is_zero: flag is NULL");
+    NPW_REQUIRE(rows >= 0 && cols >= 0, "npw_is_zero: bad sizes");
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(init_flag_kernel, dim3(1), dim3(1), 0, s, flag_dev, 1);
+    NPW_LAUNCH_CHECK();
+    if (rows * cols == 0) return NPW_OK;
+    NPW_REQUIRE(A != nullptr && lda >= cols, "npw_is_zero: bad arguments");
+    hipLaunchKernelGGL(is_zero_kernel, dim3(grid_for(rows * cols)), dim3(kThreads), 0, s, A, rows, cols,
+                       lda, atol, flag_dev);
+    NPW_LAUNCH_CHECK();
+    return NPW_OK;
+}
+
+int npw_dtranspose(int64_t rows, int64_t cols, const double* A, int64_t lda, double* B,
+                   int64_t ldb, npw_stream_t stream) {
+    if (rows <= 0 || cols <= 0) return NPW_OK;
+    NPW_REQUIRE(A != nullptr && B != nullptr && lda >= cols && ldb >= rows, "npw_dtranspose: bad arguments");
+    int64_t tiles = ceil_div(rows, 32) * ceil_div(cols, 32);
+    int grid = (int)(tiles < 65536 ? tiles : 65536);
+    hipLaunchKernelGGL(transpose_kernel, dim3(grid), dim3(256), 0, as_stream(stream), rows, cols, A, lda,
+                       B, ldb);
+    NPW_LAUNCH_CHECK();
+    return NPW_OK;
+}
+
+int npw_dtri_keep(char uplo, int unit_diag, int64_t rows, int64_t cols, double* A, int64_t lda,
+                  npw_stream_t stream) {
+    NPW_REQUIRE(uplo == 'L' || uplo == 'U' || uplo == 'l' || uplo == 'u', "npw_dtri_keep: bad uplo");
+    if (rows <= 0 || cols <= 0) return NPW_OK;
+    NPW_REQUIRE(A != nullptr && lda >= cols, "npw_dtri_keep: bad arguments");
+    hipLaunchKernelGGL(tri_keep_kernel, dim3(grid_for(rows * cols)), dim3(kThreads), 0, as_stream(stream),
+                       uplo == 'L' || uplo == 'l', unit_diag != 0, rows, cols, A, lda);
+    NPW_LAUNCH_CHECK();
+    return NPW_OK;
+}
+
+int npw_convert(int64_t rows, int64_t cols, const void* src, int64_t lds, int src_type, void* dst,
+                int64_t ldd, int dst_type, npw_stream_t stream) {
+    if (rows <= 0 || cols <= 0) return NPW_OK;
+    NPW_REQUIRE(src != nullptr && dst != nullptr && lds >= cols && ldd >= cols, "npw_convert: bad arguments");
+    NPW_REQUIRE((src_type == 0 || src_type == 1) && (dst_type == 0 || dst_type == 1), "npw_convert: bad type");
+    hipStream_t s = as_stream(stream);
+    dim3 g(grid_for(rows * cols)), b(kThreads);
+    if (src_type == 0 && dst_type == 1)
+        hipLaunchKernelGGL((convert_kernel<double, float>), g, b, 0, s, rows, cols, (const double*)src, lds, (float*)dst, ldd);
+    else if (src_type == 1 && dst_type == 0)
+        hipLaunchKernelGGL((convert_kernel<float, double>), g, b, 0, s, rows, cols, (const float*)src, lds, (double*)dst, ldd);
+    else if (src_type == 0)
+        hipLaunchKernelGGL((convert_kernel<double, double>), g, b, 0, s, rows, cols, (const double*)src, lds, (double*)dst, ldd);
+    else
+        hipLaunchKernelGGL((convert_kernel<float, float>), g, b, 0, s, rows, cols, (const float*)src, lds, (float*)dst, ldd);
+    NPW_LAUNCH_CHECK();
+    return NPW_OK;
+}
+
+int npw_fill_outer(double* A, int64_t rows, int64_t cols, int64_t lda, const double* x,
+                   int64_t row0, int64_t col0, double lambda, npw_stream_t stream) {
+    if (rows <= 0 || cols <= 0) return NPW_OK;
+    NPW_REQUIRE(A != nullptr && x != nullptr && lda >= cols, "npw_fill_outer: bad arguments");
+    hipLaunchKernelGGL(fill_outer_kernel, dim3(grid_for(rows * cols)), dim3(kThreads), 0, as_stream(stream),
+                       A, rows, cols, lda, x, row0, col0, lambda);
+    NPW_LAUNCH_CHECK();
+    return NPW_OK;
+}
+
+int npw_fill_random(double* A, int64_t rows, int64_t cols, int64_t lda, uint64_t seed,
+                    int64_t row0, int64_t col0, npw_stream_t stream) {
+    if (rows <= 0 || cols <= 0) return NPW_OK;
+    NPW_REQUIRE(A != nullptr && lda >= cols, "npw_fill_random: bad arguments");
+    hipLaunchKernelGGL(fill_random_kernel, dim3(grid_for(rows * cols)), dim3(kThreads), 0, as_stream(stream),
+                       A, rows, cols, lda, seed, row0, col0);
+    NPW_LAUNCH_CHECK();
+    return NPW_OK;
+}
+
+int npw_dsumsq(const double* A, int64_t rows, int64_t cols, int64_t lda, double* out_dev,
+               npw_stream_t stream) {
+    NPW_REQUIRE(out_dev != nullptr, "npw_dsumsq: out is NULL");
+    hipStream_t s = as_stream(stream);
+    NPW_HIP_CHECK(hipMemsetAsync(out_dev, 0, sizeof(double), s));
+    if (rows <= 0 || cols <= 0) return NPW_OK;
+    NPW_REQUIRE(A != nullptr && lda >= cols, "npw_dsumsq: bad arguments");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(rows * cols)), dim3(kThreads), 0, s, A, rows, cols, lda,
+                       out_dev);
+    NPW_LAUNCH_CHECK();
+    return NPW_OK;
+}
+
+}  // extern "C"

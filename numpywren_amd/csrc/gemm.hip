@@ -1,0 +1,455 @@
+// gemm.hip -- MFMA tile GEMM for gfx950 (MI355X):  D = alpha * op(A) op(B) + beta * C
+//
+// This is the arithmetic behind kernels.gemm / kernels.syrk / the GEMM-rich parts of
+// trsm, chol and the QR family (reference numpywren/kernels.py:239-244, 212-215).
+//
+// Design (CDNA4, wave64):
+//   * one workgroup = 256 threads = 4 waves in a 2x2 arrangement; block tile BM x BN x BK,
+//     each wave owns a (BM/2) x (BN/2) sub-tile as TM x TN MFMA 16x16 accumulators.
+//   * fp64: v_mfma_f64_16x16x4_f64 (A: lane l holds A[l&15][l>>4], B: B[l>>4][l&15],
+//     D: col = l&15, row = (l>>4) + 4*reg).  fp32: v_mfma_f32_16x16x4_f32 (same A/B
+//     maps, D row = 4*(l>>4) + reg).
+//   * operands are staged global -> registers -> LDS in 16-byte chunks, double-buffered:
+//     the loads of k-tile t+1 are issued before the MFMAs of k-tile t and written to the
+//     other LDS buffer after them; one barrier per k-tile.  Two workgroups per CU
+//     (launch_bounds(256, 2)) cover each other's barrier stalls.
+//   * each operand keeps its *natural* layout in LDS, so no transposition is needed
+//     while staging:
+//       "KC" (k contiguous in memory: A of op N, B of op T):  Xs[row][k], ld = BK + PADK
+//       "MC" (m/n contiguous in memory: A of op T, B of op N): Xs[k][col], ld = BMN + 16
+//     both paddings make the fragment ds_reads bank-conflict free (checked against the
+//     64-bank ds_read_b64 / 32-bank ds_read_b32 rules).
+//   * 1-D grid with an XCD-aware, grouped block->tile map so the 8 private L2s each see a
+//     compact patch of the output.
+//   * EDGE instantiations (any shape / alignment) guard every global access; the fast
+//     instantiations require full tiles and 16-byte aligned rows.
+#include "npw_internal.h"
+
+namespace npw {
+namespace {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
+template <typename T>
+struct MfmaTraits;
+
+template <>
+struct MfmaTraits<double> {
+    using acc_t = d4_t;
+    using vec_t = d2_t;  // 16-byte chunk
+    static constexpr int VEC = 2;
+    static constexpr int PADK = 2;  // KC row padding (elements)
+    __device__ static inline acc_t mfma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    // row of accumulator register r for lane group g (= lane >> 4)
+    __device__ static inline int acc_row(int g, int r) { return g + 4 * r; }
+};
+
+template <>
+struct MfmaTraits<float> {
+    using acc_t = f4_t;
+    using vec_t = f4_t;
+    static constexpr int VEC = 4;
+    static constexpr int PADK = 4;
+    __device__ static inline acc_t mfma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    __device__ static inline int acc_row(int g, int r) { return 4 * g + r; }
+};
+
+// k index inside a BK tile consumed by lane group g at MFMA step s.  Any bijection works
+// as long as A and B agree; fp32 pairs (2g, 2g+1) so a KC fragment is one ds_read_b64.
+template <typename T>
+__device__ inline int k_of(int s, int g);
+template <>
+__device__ inline int k_of<double>(int s, int g) {
+    return 4 * s + g;
+}
+template <>
+__device__ inline int k_of<float>(int s, int g) {
+    return 8 * (s >> 1) + 2 * g + (s & 1);
+}
+
+template <typename T>
+struct GemmParams {
+    const T* A;
+    const T* B;
+    const T* C;
+    T* D;
+    int64_t lda, ldb, ldc, ldd;
+    int M, N, K;
+    T alpha, beta;
+    const int32_t* skip0;
+    const int32_t* skip1;
+    int tiles_m, tiles_n;
+};
+
+// XCD-aware + grouped mapping of the linear block id to an output tile.
+// Blocks are dispatched round-robin over the 8 XCDs (observed; speed only): give each XCD a
+// contiguous range of the tile sequence, and order the sequence in GROUP-row bands walked
+// column-major so concurrently running blocks share A row-panels and B column-panels.
+__device__ inline void block_to_tile(int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int nwg = tiles_m * tiles_n;
+    const int b = blockIdx.x;
+    constexpr int NXCD = 8;
+    int id;
+    {
+        const int q = nwg / NXCD, r = nwg % NXCD;
+        const int xcd = b % NXCD, within = b / NXCD;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    constexpr int GROUP = 8;
+    const int band = id / (GROUP * tiles_n);
+    const int first_m = band * GROUP;
+    const int rows = min(GROUP, tiles_m - first_m);
+    const int in_band = id - band * GROUP * tiles_n;
+    tm = first_m + in_band % rows;
+    tn = in_band / rows;
+}
+
+template <typename T, int BM, int BN, int BK, bool A_KC, bool B_KC, bool EDGE>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p) {
+    using TR = MfmaTraits<T>;
+    using acc_t = typename TR::acc_t;
+    using vec_t = typename TR::vec_t;
+    constexpr int VEC = TR::VEC;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int KSTEPS = BK / 4;
+    constexpr int LDKC = BK + TR::PADK;
+    constexpr int LDA_MC = BM + 16, LDB_MC = BN + 16;
+    constexpr int A_ELEMS = A_KC ? BM * LDKC : BK * LDA_MC;
+    constexpr int B_ELEMS = B_KC ? BN * LDKC : BK * LDB_MC;
+    constexpr int A_CHUNKS = BM * BK / VEC / 256;
+    constexpr int B_CHUNKS = BN * BK / VEC / 256;
+    static_assert(A_CHUNKS >= 1 && B_CHUNKS >= 1, "tile too small for 256 threads");
+    static_assert(BK % 8 == 0, "BK");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    T* As[2] = {smem, smem + A_ELEMS + B_ELEMS};
+    T* Bs[2] = {smem + A_ELEMS, smem + 2 * A_ELEMS + B_ELEMS};
+
+    int tile_m, tile_n;
+    block_to_tile(p.tiles_m, p.tiles_n, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+    const int li = lane & 15, lg = lane >> 4;
+
+    int nk = (p.K + BK - 1) / BK;
+    if ((p.skip0 && *p.skip0) || (p.skip1 && *p.skip1)) nk = 0;
+
+    acc_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0;
+
+    vec_t ra[A_CHUNKS], rb[B_CHUNKS];
+
+    // ---- global -> registers ------------------------------------------------------------
+    auto load_tiles = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int c = 0; c < A_CHUNKS; ++c) {
+            const int id = tid + 256 * c;
+            if constexpr (A_KC) {  // A stored M x K
+                const int row = id / (BK / VEC), kc = (id % (BK / VEC)) * VEC;
+                const T* src = p.A + (int64_t)(m0 + row) * p.lda + (k0 + kc);
+                if constexpr (!EDGE) {
+                    ra[c] = *reinterpret_cast<const vec_t*>(src);
+                } else {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v)
+                        ra[c][v] = (m0 + row < p.M && k0 + kc + v < p.K) ? src[v] : T(0);
+                }
+            } else {  // A stored K x M
+                const int kk = id / (BM / VEC), mc = (id % (BM / VEC)) * VEC;
+                const T* src = p.A + (int64_t)(k0 + kk) * p.lda + (m0 + mc);
+                if constexpr (!EDGE) {
+                    ra[c] = *reinterpret_cast<const vec_t*>(src);
+                } else {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v)
+                        ra[c][v] = (k0 + kk < p.K && m0 + mc + v < p.M) ? src[v] : T(0);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < B_CHUNKS; ++c) {
+            const int id = tid + 256 * c;
+            if constexpr (B_KC) {  // B stored N x K
+                const int row = id / (BK / VEC), kc = (id % (BK / VEC)) * VEC;
+                const T* src = p.B + (int64_t)(n0 + row) * p.ldb + (k0 + kc);
+                if constexpr (!EDGE) {
+                    rb[c] = *reinterpret_cast<const vec_t*>(src);
+                } else {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v)
+                        rb[c][v] = (n0 + row < p.N && k0 + kc + v < p.K) ? src[v] : T(0);
+                }
+            } else {  // B stored K x N
+                const int kk = id / (BN / VEC), nc = (id % (BN / VEC)) * VEC;
+                const T* src = p.B + (int64_t)(k0 + kk) * p.ldb + (n0 + nc);
+                if constexpr (!EDGE) {
+                    rb[c] = *reinterpret_cast<const vec_t*>(src);
+                } else {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v)
+                        rb[c][v] = (k0 + kk < p.K && n0 + nc + v < p.N) ? src[v] : T(0);
+                }
+            }
+        }
+    };
+
+    // ---- registers -> LDS -----------------------------------------------------------------
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int c = 0; c < A_CHUNKS; ++c) {
+            const int id = tid + 256 * c;
+            if constexpr (A_KC) {
+                const int row = id / (BK / VEC), kc = (id % (BK / VEC)) * VEC;
+                *reinterpret_cast<vec_t*>(&As[buf][row * LDKC + kc]) = ra[c];
+            } else {
+                const int kk = id / (BM / VEC), mc = (id % (BM / VEC)) * VEC;
+                *reinterpret_cast<vec_t*>(&As[buf][kk * LDA_MC + mc]) = ra[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < B_CHUNKS; ++c) {
+            const int id = tid + 256 * c;
+            if constexpr (B_KC) {
+                const int row = id / (BK / VEC), kc = (id % (BK / VEC)) * VEC;
+                *reinterpret_cast<vec_t*>(&Bs[buf][row * LDKC + kc]) = rb[c];
+            } else {
+                const int kk = id / (BN / VEC), nc = (id % (BN / VEC)) * VEC;
+                *reinterpret_cast<vec_t*>(&Bs[buf][kk * LDB_MC + nc]) = rb[c];
+            }
+        }
+    };
+
+    // ---- LDS -> fragments -> MFMA ----------------------------------------------------------
+    auto compute = [&](int buf) {
+        const T* a_s = As[buf];
+        const T* b_s = Bs[buf];
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const int kk = k_of<T>(s, lg);
+            T af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (A_KC)
+                    af[i] = a_s[(wm0 + 16 * i + li) * LDKC + kk];
+                else
+                    af[i] = a_s[kk * LDA_MC + wm0 + 16 * i + li];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (B_KC)
+                    bf[j] = b_s[(wn0 + 16 * j + li) * LDKC + kk];
+                else
+                    bf[j] = b_s[kk * LDB_MC + wn0 + 16 * j + li];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = TR::mfma(af[i], bf[j], acc[i][j]);
+        }
+    };
+
+    if (nk > 0) {
+        load_tiles(0);
+        store_tiles(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) load_tiles(kt + 1);
+            compute(cur);
+            if (kt + 1 < nk) store_tiles(cur ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: D = alpha * acc + beta * C ------------------------------------------------
+    const T alpha = p.alpha, beta = p.beta;
+    // (the beta test is hoisted out of the unrolled loops: a per-element "load or not" select
+    //  makes hipcc branch around and wait for every single load)
+    if (beta != T(0)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            T cv[TN][4];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn0 + 16 * j + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + wm0 + 16 * i + TR::acc_row(lg, r);
+                    const bool ok = !EDGE || (row < p.M && col < p.N);
+                    cv[j][r] = ok ? p.C[(int64_t)row * p.ldc + col] : T(0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn0 + 16 * j + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + wm0 + 16 * i + TR::acc_row(lg, r);
+                    if (EDGE && (row >= p.M || col >= p.N)) continue;
+                    p.D[(int64_t)row * p.ldd + col] = fma(beta, cv[j][r], alpha * acc[i][j][r]);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn0 + 16 * j + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + wm0 + 16 * i + TR::acc_row(lg, r);
+                    if (EDGE && (row >= p.M || col >= p.N)) continue;
+                    p.D[(int64_t)row * p.ldd + col] = alpha * acc[i][j][r];
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int BK, bool A_KC, bool B_KC, bool EDGE>
+int launch(const GemmParams<T>& p, hipStream_t stream) {
+    using TR = MfmaTraits<T>;
+    constexpr int LDKC = BK + TR::PADK;
+    constexpr int A_ELEMS = A_KC ? BM * LDKC : BK * (BM + 16);
+    constexpr int B_ELEMS = B_KC ? BN * LDKC : BK * (BN + 16);
+    constexpr size_t smem = 2 * (A_ELEMS + B_ELEMS) * sizeof(T);
+    auto kern = gemm_kernel<T, BM, BN, BK, A_KC, B_KC, EDGE>;
+    static thread_local bool attr_set = false;
+    if (!attr_set && smem > 48 * 1024) {
+        NPW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    const int nwg = p.tiles_m * p.tiles_n;
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), smem, stream, p);
+    NPW_LAUNCH_CHECK();
+    return NPW_OK;
+}
+
+template <typename T, int BM, int BN, int BK, bool EDGE>
+int dispatch_layout(bool a_kc, bool b_kc, const GemmParams<T>& p, hipStream_t s) {
+    if (a_kc && b_kc) return launch<T, BM, BN, BK, true, true, EDGE>(p, s);
+    if (a_kc && !b_kc) return launch<T, BM, BN, BK, true, false, EDGE>(p, s);
+    if (!a_kc && b_kc) return launch<T, BM, BN, BK, false, true, EDGE>(p, s);
+    return launch<T, BM, BN, BK, false, false, EDGE>(p, s);
+}
+
+}  // namespace
+
+template <typename T>
+int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A,
+         int64_t lda, const T* B, int64_t ldb, T beta, const T* C, int64_t ldc, T* D, int64_t ldd,
+         const int32_t* skip0, const int32_t* skip1, hipStream_t stream) {
+    const bool ta = (transA == 'T' || transA == 't');
+    const bool tb = (transB == 'T' || transB == 't');
+    NPW_REQUIRE(ta || transA == 'N' || transA == 'n', "gemm: bad transA '%c'", transA);
+    NPW_REQUIRE(tb || transB == 'N' || transB == 'n', "gemm: bad transB '%c'", transB);
+    NPW_REQUIRE(m >= 0 && n >= 0 && k >= 0, "gemm: negative dimension");
+    NPW_REQUIRE(m < (1LL << 30) && n < (1LL << 30) && k < (1LL << 30), "gemm: dimension too large");
+    if (m == 0 || n == 0) return NPW_OK;
+    NPW_REQUIRE(D != nullptr, "gemm: D is NULL");
+    NPW_REQUIRE(beta == T(0) || C != nullptr, "gemm: C is NULL with beta != 0");
+    NPW_REQUIRE(k == 0 || (A != nullptr && B != nullptr), "gemm: A/B NULL");
+    NPW_REQUIRE(lda >= (ta ? m : k) && ldb >= (tb ? k : n) && ldd >= n && (beta == T(0) || ldc >= n),
+                "gemm: leading dimension too small (m=%lld n=%lld k=%lld lda=%lld ldb=%lld ldc=%lld "
+                "ldd=%lld)",
+                (long long)m, (long long)n, (long long)k, (long long)lda, (long long)ldb,
+                (long long)ldc, (long long)ldd);
+
+    GemmParams<T> p;
+    p.A = A;
+    p.B = B;
+    p.C = C;
+    p.D = D;
+    p.lda = lda;
+    p.ldb = ldb;
+    p.ldc = ldc;
+    p.ldd = ldd;
+    p.M = (int)m;
+    p.N = (int)n;
+    p.K = (int)k;
+    p.alpha = alpha;
+    p.beta = beta;
+    p.skip0 = skip0;
+    p.skip1 = skip1;
+
+    const bool a_kc = !ta;  // A stored M x K  => k contiguous
+    const bool b_kc = tb;   // B stored N x K  => k contiguous
+    constexpr int VEC = 16 / (int)sizeof(T);
+    auto aligned16 = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
+    const bool vec_ok = aligned16(A) && aligned16(B) && (lda % VEC == 0) && (ldb % VEC == 0);
+    constexpr int BK = 16;
+    const bool k_ok = (k % BK == 0);
+
+    // tile selection: 128x128 when it fills the chip (or the problem is large), else 64x64
+    const int64_t wg128 = ceil_div(m, 128) * ceil_div(n, 128);
+    const bool big = (wg128 >= 192);
+    if (big) {
+        p.tiles_m = (int)ceil_div(m, 128);
+        p.tiles_n = (int)ceil_div(n, 128);
+        const bool full = vec_ok && k_ok && (m % 128 == 0) && (n % 128 == 0);
+        if (full) return dispatch_layout<T, 128, 128, BK, false>(a_kc, b_kc, p, stream);
+        return dispatch_layout<T, 128, 128, BK, true>(a_kc, b_kc, p, stream);
+    }
+    p.tiles_m = (int)ceil_div(m, 64);
+    p.tiles_n = (int)ceil_div(n, 64);
+    const bool full = vec_ok && k_ok && (m % 64 == 0) && (n % 64 == 0);
+    if (full) return dispatch_layout<T, 64, 64, BK, false>(a_kc, b_kc, p, stream);
+    return dispatch_layout<T, 64, 64, BK, true>(a_kc, b_kc, p, stream);
+}
+
+template int gemm<double>(char, char, int64_t, int64_t, int64_t, double, const double*, int64_t,
+                          const double*, int64_t, double, const double*, int64_t, double*, int64_t,
+                          const int32_t*, const int32_t*, hipStream_t);
+template int gemm<float>(char, char, int64_t, int64_t, int64_t, float, const float*, int64_t,
+                         const float*, int64_t, float, const float*, int64_t, float*, int64_t,
+                         const int32_t*, const int32_t*, hipStream_t);
+
+}  // namespace npw
+
+extern "C" {
+
+int npw_dgemm(char transA, char transB, int64_t m, int64_t n, int64_t k, double alpha,
+              const double* A, int64_t lda, const double* B, int64_t ldb, double beta,
+              const double* C, int64_t ldc, double* D, int64_t ldd, const int32_t* skip_flag,
+              npw_stream_t stream) {
+    return npw::gemm<double>(transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, D, ldd,
+                             skip_flag, nullptr, npw::as_stream(stream));
+}
+
+int npw_sgemm(char transA, char transB, int64_t m, int64_t n, int64_t k, float alpha,
+              const float* A, int64_t lda, const float* B, int64_t ldb, float beta, const float* C,
+              int64_t ldc, float* D, int64_t ldd, const int32_t* skip_flag, npw_stream_t stream) {
+    return npw::gemm<float>(transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, D, ldd,
+                            skip_flag, nullptr, npw::as_stream(stream));
+}
+
+int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t lds,
+                     const double* X, int64_t ldx, const double* Y, int64_t ldy, double* D,
+                     int64_t ldd, const int32_t* skip_x, const int32_t* skip_y,
+                     npw_stream_t stream) {
+    return npw::gemm<double>('N', 'T', m, n, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, skip_x,
+                             skip_y, npw::as_stream(stream));
+}
+
+}  // extern "C"

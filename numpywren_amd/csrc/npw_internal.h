@@ -1,0 +1,51 @@
+// Internal helpers shared by the libnpw_hip.so translation units (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "npw_hip.h"
+
+namespace npw {
+
+// thread-local error message behind npw_last_error()
+char* error_buffer();
+int set_error(int code, const char* fmt, ...);
+
+#define NPW_HIP_CHECK(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return ::npw::set_error(NPW_ERR_HIP, "%s failed: %s (%s:%d)", #expr,              \
+                                    hipGetErrorString(_e), __FILE__, __LINE__);               \
+    } while (0)
+
+#define NPW_LAUNCH_CHECK()                                                                    \
+    do {                                                                                      \
+        hipError_t _e = hipGetLastError();                                                    \
+        if (_e != hipSuccess)                                                                 \
+            return ::npw::set_error(NPW_ERR_HIP, "kernel launch failed: %s (%s:%d)",          \
+                                    hipGetErrorString(_e), __FILE__, __LINE__);               \
+    } while (0)
+
+#define NPW_REQUIRE(cond, ...)                                                                \
+    do {                                                                                      \
+        if (!(cond)) return ::npw::set_error(NPW_ERR_ARG, __VA_ARGS__);                       \
+    } while (0)
+
+static inline hipStream_t as_stream(npw_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- internal (C++) entry points used across translation units -------------------------
+
+// D = alpha * op(A) op(B) + beta * C  with two optional skip flags (either set => no product)
+template <typename T>
+int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A,
+         int64_t lda, const T* B, int64_t ldb, T beta, const T* C, int64_t ldc, T* D, int64_t ldd,
+         const int32_t* skip0, const int32_t* skip1, hipStream_t stream);
+
+}  // namespace npw

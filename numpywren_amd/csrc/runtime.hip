@@ -1,0 +1,252 @@
+// runtime.hip -- device, memory, stream and event entry points of libnpw_hip.so.
+//
+// These replace the reference's storage / worker plumbing: S3 object GET/PUT of tiles
+// (reference numpywren/matrix.py:497-533) becomes HBM allocations plus pinned-host async
+// copies; the pywren worker pool and its asyncio read/compute/write pipeline (reference
+// numpywren/job_runner.py:224-370) becomes HIP streams and events driven by the host.
+#include "npw_internal.h"
+
+namespace npw {
+
+char* error_buffer() {
+    static thread_local char buf[1024] = {0};
+    return buf;
+}
+
+int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(error_buffer(), 1024, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+}  // namespace npw
+
+using npw::as_stream;
+
+extern "C" {
+
+int npw_version(void) { return 100; }
+
+const char* npw_last_error(void) { return npw::error_buffer(); }
+
+int npw_device_count(int* count) {
+    NPW_REQUIRE(count != nullptr, "npw_device_count: NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *count = 0;
+        return npw::set_error(NPW_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    }
+    *count = c;
+    return NPW_OK;
+}
+
+int npw_set_device(int device) {
+    NPW_HIP_CHECK(hipSetDevice(device));
+    return NPW_OK;
+}
+
+int npw_get_device(int* device) {
+    NPW_REQUIRE(device != nullptr, "npw_get_device: NULL");
+    NPW_HIP_CHECK(hipGetDevice(device));
+    return NPW_OK;
+}
+
+int npw_device_info(int device, char* name, size_t name_len, size_t* total_mem_bytes,
+                    int* compute_units, int* clock_khz) {
+    hipDeviceProp_t prop;
+    NPW_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (name && name_len) {
+        strncpy(name, prop.gcnArchName, name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (total_mem_bytes) *total_mem_bytes = prop.totalGlobalMem;
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (clock_khz) *clock_khz = prop.clockRate;
+    return NPW_OK;
+}
+
+int npw_mem_info(size_t* free_bytes, size_t* total_bytes) {
+    size_t f = 0, t = 0;
+    NPW_HIP_CHECK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return NPW_OK;
+}
+
+int npw_malloc(void** dptr, size_t bytes) {
+    NPW_REQUIRE(dptr != nullptr, "npw_malloc: NULL");
+    *dptr = nullptr;
+    if (bytes == 0) return NPW_OK;
+    NPW_HIP_CHECK(hipMalloc(dptr, bytes));
+    return NPW_OK;
+}
+
+int npw_free(void* dptr) {
+    if (dptr) NPW_HIP_CHECK(hipFree(dptr));
+    return NPW_OK;
+}
+
+int npw_host_alloc(void** hptr, size_t bytes) {
+    NPW_REQUIRE(hptr != nullptr, "npw_host_alloc: NULL");
+    *hptr = nullptr;
+    if (bytes == 0) return NPW_OK;
+    NPW_HIP_CHECK(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+    return NPW_OK;
+}
+
+int npw_host_free(void* hptr) {
+    if (hptr) NPW_HIP_CHECK(hipHostFree(hptr));
+    return NPW_OK;
+}
+
+int npw_memcpy_h2d_async(void* dst, const void* src, size_t bytes, npw_stream_t stream) {
+    if (bytes == 0) return NPW_OK;
+    NPW_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    return NPW_OK;
+}
+
+int npw_memcpy_d2h_async(void* dst, const void* src, size_t bytes, npw_stream_t stream) {
+    if (bytes == 0) return NPW_OK;
+    NPW_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    return NPW_OK;
+}
+
+int npw_memcpy_d2d_async(void* dst, const void* src, size_t bytes, npw_stream_t stream) {
+    if (bytes == 0) return NPW_OK;
+    NPW_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+    return NPW_OK;
+}
+
+int npw_memcpy_peer_async(void* dst, int dst_device, const void* src, int src_device, size_t bytes,
+                          npw_stream_t stream) {
+    if (bytes == 0) return NPW_OK;
+    NPW_HIP_CHECK(hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, as_stream(stream)));
+    return NPW_OK;
+}
+
+int npw_memset_async(void* dst, int byte_value, size_t bytes, npw_stream_t stream) {
+    if (bytes == 0) return NPW_OK;
+    NPW_HIP_CHECK(hipMemsetAsync(dst, byte_value, bytes, as_stream(stream)));
+    return NPW_OK;
+}
+
+int npw_memcpy2d_h2d_async(void* dst, size_t dpitch, const void* src, size_t spitch,
+                           size_t row_bytes, size_t rows, npw_stream_t stream) {
+    if (row_bytes == 0 || rows == 0) return NPW_OK;
+    NPW_HIP_CHECK(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows,
+                                   hipMemcpyHostToDevice, as_stream(stream)));
+    return NPW_OK;
+}
+
+int npw_memcpy2d_d2h_async(void* dst, size_t dpitch, const void* src, size_t spitch,
+                           size_t row_bytes, size_t rows, npw_stream_t stream) {
+    if (row_bytes == 0 || rows == 0) return NPW_OK;
+    NPW_HIP_CHECK(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows,
+                                   hipMemcpyDeviceToHost, as_stream(stream)));
+    return NPW_OK;
+}
+
+int npw_memcpy2d_d2d_async(void* dst, size_t dpitch, const void* src, size_t spitch,
+                           size_t row_bytes, size_t rows, npw_stream_t stream) {
+    if (row_bytes == 0 || rows == 0) return NPW_OK;
+    NPW_HIP_CHECK(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows,
+                                   hipMemcpyDeviceToDevice, as_stream(stream)));
+    return NPW_OK;
+}
+
+int npw_stream_create(npw_stream_t* stream, int high_priority) {
+    NPW_REQUIRE(stream != nullptr, "npw_stream_create: NULL");
+    hipStream_t s;
+    if (high_priority) {
+        int lo = 0, hi = 0;
+        NPW_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        NPW_HIP_CHECK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi));
+    } else {
+        NPW_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    }
+    *stream = reinterpret_cast<npw_stream_t>(s);
+    return NPW_OK;
+}
+
+int npw_stream_destroy(npw_stream_t stream) {
+    if (stream) NPW_HIP_CHECK(hipStreamDestroy(as_stream(stream)));
+    return NPW_OK;
+}
+
+int npw_stream_synchronize(npw_stream_t stream) {
+    NPW_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+    return NPW_OK;
+}
+
+int npw_stream_query(npw_stream_t stream, int* done) {
+    NPW_REQUIRE(done != nullptr, "npw_stream_query: NULL");
+    hipError_t e = hipStreamQuery(as_stream(stream));
+    if (e == hipSuccess) {
+        *done = 1;
+    } else if (e == hipErrorNotReady) {
+        *done = 0;
+        (void)hipGetLastError();
+    } else {
+        return npw::set_error(NPW_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(e));
+    }
+    return NPW_OK;
+}
+
+int npw_device_synchronize(void) {
+    NPW_HIP_CHECK(hipDeviceSynchronize());
+    return NPW_OK;
+}
+
+int npw_event_create(npw_event_t* event, int timing) {
+    NPW_REQUIRE(event != nullptr, "npw_event_create: NULL");
+    hipEvent_t e;
+    NPW_HIP_CHECK(hipEventCreateWithFlags(&e, timing ? hipEventDefault : hipEventDisableTiming));
+    *event = reinterpret_cast<npw_event_t>(e);
+    return NPW_OK;
+}
+
+int npw_event_destroy(npw_event_t event) {
+    if (event) NPW_HIP_CHECK(hipEventDestroy(reinterpret_cast<hipEvent_t>(event)));
+    return NPW_OK;
+}
+
+int npw_event_record(npw_event_t event, npw_stream_t stream) {
+    NPW_HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(event), as_stream(stream)));
+    return NPW_OK;
+}
+
+int npw_event_synchronize(npw_event_t event) {
+    NPW_HIP_CHECK(hipEventSynchronize(reinterpret_cast<hipEvent_t>(event)));
+    return NPW_OK;
+}
+
+int npw_event_query(npw_event_t event, int* done) {
+    NPW_REQUIRE(done != nullptr, "npw_event_query: NULL");
+    hipError_t e = hipEventQuery(reinterpret_cast<hipEvent_t>(event));
+    if (e == hipSuccess) {
+        *done = 1;
+    } else if (e == hipErrorNotReady) {
+        *done = 0;
+        (void)hipGetLastError();
+    } else {
+        return npw::set_error(NPW_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
+    }
+    return NPW_OK;
+}
+
+int npw_stream_wait_event(npw_stream_t stream, npw_event_t event) {
+    NPW_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), reinterpret_cast<hipEvent_t>(event), 0));
+    return NPW_OK;
+}
+
+int npw_event_elapsed_ms(npw_event_t start, npw_event_t stop, float* ms) {
+    NPW_REQUIRE(ms != nullptr, "npw_event_elapsed_ms: NULL");
+    NPW_HIP_CHECK(hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start),
+                                      reinterpret_cast<hipEvent_t>(stop)));
+    return NPW_OK;
+}
+
+}  // extern "C"

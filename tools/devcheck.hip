@@ -1,0 +1,213 @@
+// devcheck -- developer harness (not part of the product): checks libnpw_hip GEMM variants
+// against a naive host loop on small shapes and times the 4096^3 trailing update + an MFMA
+// issue-rate microbenchmark.  Build: make -C numpywren_amd/csrc devcheck
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "npw_hip.h"
+
+#define CK(x)                                                              \
+    do {                                                                   \
+        int _r = (x);                                                      \
+        if (_r != 0) {                                                     \
+            printf("FAIL %s -> %d: %s\n", #x, _r, npw_last_error());       \
+            exit(1);                                                       \
+        }                                                                  \
+    } while (0)
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+__global__ void mfma_f64_peak(double* out, int iters) {
+    d4_t acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = {0, 0, 0, 0};
+    double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void mfma_f32_peak(float* out, int iters) {
+    f4_t acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = {0, 0, 0, 0};
+    float a = threadIdx.x * 1e-3f, b = 1.0f + threadIdx.x * 1e-4f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+static double urand() { return (double)rand() / RAND_MAX * 2.0 - 1.0; }
+
+template <typename T>
+static double check_gemm(char ta, char tb, int m, int n, int k, int pad) {
+    const int a_rows = (ta == 'N') ? m : k, a_cols = (ta == 'N') ? k : m;
+    const int b_rows = (tb == 'N') ? k : n, b_cols = (tb == 'N') ? n : k;
+    const int lda = a_cols + pad, ldb = b_cols + pad, ldc = n + pad, ldd = n + pad;
+    std::vector<T> A((size_t)a_rows * lda), B((size_t)b_rows * ldb), C((size_t)m * ldc), D((size_t)m * ldd, 0);
+    for (auto& x : A) x = (T)urand();
+    for (auto& x : B) x = (T)urand();
+    for (auto& x : C) x = (T)urand();
+    T *dA, *dB, *dC, *dD;
+    CK(npw_malloc((void**)&dA, A.size() * sizeof(T) + 16));
+    CK(npw_malloc((void**)&dB, B.size() * sizeof(T) + 16));
+    CK(npw_malloc((void**)&dC, C.size() * sizeof(T) + 16));
+    CK(npw_malloc((void**)&dD, D.size() * sizeof(T) + 16));
+    CK(npw_memcpy_h2d_async(dA, A.data(), A.size() * sizeof(T), 0));
+    CK(npw_memcpy_h2d_async(dB, B.data(), B.size() * sizeof(T), 0));
+    CK(npw_memcpy_h2d_async(dC, C.data(), C.size() * sizeof(T), 0));
+    CK(npw_memset_async(dD, 0, D.size() * sizeof(T), 0));
+    const T alpha = (T)-1.0, beta = (T)1.0;
+    if (sizeof(T) == 8)
+        CK(npw_dgemm(ta, tb, m, n, k, alpha, (double*)dA, lda, (double*)dB, ldb, beta, (double*)dC, ldc,
+                     (double*)dD, ldd, nullptr, 0));
+    else
+        CK(npw_sgemm(ta, tb, m, n, k, alpha, (float*)dA, lda, (float*)dB, ldb, beta, (float*)dC, ldc,
+                     (float*)dD, ldd, nullptr, 0));
+    CK(npw_memcpy_d2h_async(D.data(), dD, D.size() * sizeof(T), 0));
+    CK(npw_device_synchronize());
+    double maxerr = 0;
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < n; ++j) {
+            double s = 0;
+            for (int kk = 0; kk < k; ++kk) {
+                double a = (ta == 'N') ? A[(size_t)i * lda + kk] : A[(size_t)kk * lda + i];
+                double b = (tb == 'N') ? B[(size_t)kk * ldb + j] : B[(size_t)j * ldb + kk];
+                s += a * b;
+            }
+            double ref = (double)beta * C[(size_t)i * ldc + j] + (double)alpha * s;
+            maxerr = std::fmax(maxerr, std::fabs(ref - (double)D[(size_t)i * ldd + j]));
+        }
+    // padding columns of D must be untouched
+    for (int i = 0; i < m; ++i)
+        for (int j = n; j < ldd; ++j)
+            if (D[(size_t)i * ldd + j] != 0) maxerr = 1e30;
+    npw_free(dA);
+    npw_free(dB);
+    npw_free(dC);
+    npw_free(dD);
+    return maxerr;
+}
+
+int main(int argc, char** argv) {
+    int ndev = 0;
+    CK(npw_device_count(&ndev));
+    char name[128];
+    size_t mem;
+    int cus, khz;
+    CK(npw_device_info(0, name, sizeof(name), &mem, &cus, &khz));
+    printf("device0: %s  mem=%.1f GiB  CUs=%d  clock=%d kHz  (ndev=%d)\n", name, mem / 1073741824.0, cus, khz, ndev);
+
+    // ---- correctness on assorted shapes ------------------------------------------------
+    int bad = 0;
+    const char tr[2] = {'N', 'T'};
+    struct Shape { int m, n, k, pad; };
+    Shape shapes[] = {{8, 8, 8, 0},     {7, 5, 3, 0},     {64, 64, 16, 0},   {128, 128, 32, 0},
+                      {100, 37, 19, 1}, {256, 192, 48, 0}, {130, 257, 33, 3}, {2048, 2048, 64, 0},
+                      {2048, 1920, 40, 0}, {1, 1, 1, 0}, {16, 16, 0, 0}};
+    for (auto sh : shapes)
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b) {
+                double e64 = check_gemm<double>(tr[a], tr[b], sh.m, sh.n, sh.k, sh.pad);
+                double e32 = check_gemm<float>(tr[a], tr[b], sh.m, sh.n, sh.k, sh.pad);
+                bool ok = e64 < 1e-12 * (sh.k + 1) && e32 < 2e-6 * (sh.k + 1);
+                if (!ok) ++bad;
+                printf("gemm %c%c m=%d n=%d k=%d pad=%d  err64=%.3e err32=%.3e %s\n", tr[a], tr[b], sh.m,
+                       sh.n, sh.k, sh.pad, e64, e32, ok ? "ok" : "BAD");
+            }
+    printf("correctness: %s (%d bad)\n", bad ? "FAILED" : "PASSED", bad);
+
+    // ---- MFMA issue-rate microbenchmarks ---------------------------------------------------
+    {
+        double* out;
+        CK(npw_malloc((void**)&out, 256 * 8 * 256 * 8));
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        const int iters = 20000;
+        for (int waves = 1; waves <= 2; ++waves) {
+            int blocks = 256 * waves;  // 256 threads = 1 wave / SIMD per block
+            hipLaunchKernelGGL(mfma_f64_peak, dim3(blocks), dim3(256), 0, 0, out, 100);
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(mfma_f64_peak, dim3(blocks), dim3(256), 0, 0, out, iters);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            double flops = (double)blocks * 4 * iters * 8 * 2.0 * 16 * 16 * 4;
+            printf("mfma_f64_16x16x4 peak (%d waves/SIMD): %.2f TFLOP/s  (%.3f ms)\n", waves, flops / ms / 1e9, ms);
+            hipLaunchKernelGGL(mfma_f32_peak, dim3(blocks), dim3(256), 0, 0, (float*)out, 100);
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(mfma_f32_peak, dim3(blocks), dim3(256), 0, 0, (float*)out, iters);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+            printf("mfma_f32_16x16x4 peak (%d waves/SIMD): %.2f TFLOP/s  (%.3f ms)\n", waves, flops / ms / 1e9, ms);
+        }
+        npw_free(out);
+    }
+
+    // ---- 4096^3 timings ------------------------------------------------------------------
+    {
+        const int n = (argc > 1) ? atoi(argv[1]) : 4096;
+        size_t bytes = (size_t)n * n * 8;
+        double *S, *X, *Y, *D;
+        CK(npw_malloc((void**)&S, bytes));
+        CK(npw_malloc((void**)&X, bytes));
+        CK(npw_malloc((void**)&Y, bytes));
+        CK(npw_malloc((void**)&D, bytes));
+        CK(npw_fill_random(S, n, n, n, 1, 0, 0, 0));
+        CK(npw_fill_random(X, n, n, n, 2, 0, 0, 0));
+        CK(npw_fill_random(Y, n, n, n, 3, 0, 0, 0));
+        npw_event_t e0, e1;
+        CK(npw_event_create(&e0, 1));
+        CK(npw_event_create(&e1, 1));
+        const char* names[4] = {"NN", "NT(syrk)", "TN", "TT"};
+        for (int v = 0; v < 4; ++v) {
+            char ta = (v & 2) ? 'T' : 'N', tb = (v & 1) ? 'T' : 'N';
+            for (int w = 0; w < 2; ++w)
+                CK(npw_dgemm(ta, tb, n, n, n, -1.0, X, n, Y, n, 1.0, S, n, D, n, nullptr, 0));
+            const int reps = 10;
+            CK(npw_event_record(e0, 0));
+            for (int r = 0; r < reps; ++r)
+                CK(npw_dgemm(ta, tb, n, n, n, -1.0, X, n, Y, n, 1.0, S, n, D, n, nullptr, 0));
+            CK(npw_event_record(e1, 0));
+            CK(npw_event_synchronize(e1));
+            float ms;
+            CK(npw_event_elapsed_ms(e0, e1, &ms));
+            ms /= reps;
+            printf("dgemm %s n=%d: %.3f ms  %.2f TFLOP/s\n", names[v], n, ms, 2.0 * n * n * (double)n / ms / 1e9);
+        }
+        float *Xf = (float*)X, *Yf = (float*)Y, *Df = (float*)D;
+        CK(npw_convert(n, n, S, n, 0, Xf, n, 1, 0));
+        CK(npw_convert(n, n, S, n, 0, Yf, n, 1, 0));
+        for (int v = 0; v < 4; ++v) {
+            char ta = (v & 2) ? 'T' : 'N', tb = (v & 1) ? 'T' : 'N';
+            for (int w = 0; w < 2; ++w)
+                CK(npw_sgemm(ta, tb, n, n, n, 1.0f, Xf, n, Yf, n, 0.0f, nullptr, n, Df, n, nullptr, 0));
+            const int reps = 10;
+            CK(npw_event_record(e0, 0));
+            for (int r = 0; r < reps; ++r)
+                CK(npw_sgemm(ta, tb, n, n, n, 1.0f, Xf, n, Yf, n, 0.0f, nullptr, n, Df, n, nullptr, 0));
+            CK(npw_event_record(e1, 0));
+            CK(npw_event_synchronize(e1));
+            float ms;
+            CK(npw_event_elapsed_ms(e0, e1, &ms));
+            ms /= reps;
+            printf("sgemm %s n=%d: %.3f ms  %.2f TFLOP/s\n", names[v], n, ms, 2.0 * n * n * (double)n / ms / 1e9);
+        }
+    }
+    return bad ? 1 : 0;
+}
