@@ -86,6 +86,7 @@ struct GemmParams {
     const int32_t* skip0;
     const int32_t* skip1;
     int tiles_m, tiles_n;
+    int lower_only;
 };
 
 // XCD-aware + grouped mapping of the linear block id to an output tile.
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p) {
     int tile_m, tile_n;
     block_to_tile(p.tiles_m, p.tiles_n, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    if (p.lower_only && n0 > m0 + BM - 1) return;  // tile entirely above the diagonal
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -359,7 +361,7 @@ int dispatch_layout(bool a_kc, bool b_kc, const GemmParams<T>& p, hipStream_t s)
 template <typename T>
 int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A,
          int64_t lda, const T* B, int64_t ldb, T beta, const T* C, int64_t ldc, T* D, int64_t ldd,
-         const int32_t* skip0, const int32_t* skip1, hipStream_t stream) {
+         const GemmOpts& opts, hipStream_t stream) {
     const bool ta = (transA == 'T' || transA == 't');
     const bool tb = (transB == 'T' || transB == 't');
     NPW_REQUIRE(ta || transA == 'N' || transA == 'n', "gemm: bad transA '%c'", transA);
@@ -390,8 +392,9 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
     p.K = (int)k;
     p.alpha = alpha;
     p.beta = beta;
-    p.skip0 = skip0;
-    p.skip1 = skip1;
+    p.skip0 = opts.skip0;
+    p.skip1 = opts.skip1;
+    p.lower_only = opts.lower_only ? 1 : 0;
 
     const bool a_kc = !ta;  // A stored M x K  => k contiguous
     const bool b_kc = tb;   // B stored N x K  => k contiguous
@@ -401,6 +404,17 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
     constexpr int BK = 16;
     const bool k_ok = (k % BK == 0);
 
+    if (opts.inplace_a) {
+        // D aliases A: legal because with a single tile column every workgroup reads only the rows
+        // it later writes, and its reads complete (k-loop) before its epilogue stores.
+        NPW_REQUIRE(!ta && n <= 128 && k <= 128 && (void*)D == (void*)A && ldd == lda,
+                    "gemm: inplace_a needs op(A)=N, n,k <= 128 and D == A");
+        p.tiles_m = (int)ceil_div(m, 64);
+        p.tiles_n = 1;
+        const bool full = vec_ok && k_ok && (m % 64 == 0) && (n == 128);
+        if (full) return dispatch_layout<T, 64, 128, BK, false>(a_kc, b_kc, p, stream);
+        return dispatch_layout<T, 64, 128, BK, true>(a_kc, b_kc, p, stream);
+    }
     // tile selection: 128x128 when it fills the chip (or the problem is large), else 64x64
     const int64_t wg128 = ceil_div(m, 128) * ceil_div(n, 128);
     const bool big = (wg128 >= 192);
@@ -420,10 +434,10 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
 
 template int gemm<double>(char, char, int64_t, int64_t, int64_t, double, const double*, int64_t,
                           const double*, int64_t, double, const double*, int64_t, double*, int64_t,
-                          const int32_t*, const int32_t*, hipStream_t);
+                          const GemmOpts&, hipStream_t);
 template int gemm<float>(char, char, int64_t, int64_t, int64_t, float, const float*, int64_t,
                          const float*, int64_t, float, const float*, int64_t, float*, int64_t,
-                         const int32_t*, const int32_t*, hipStream_t);
+                         const GemmOpts&, hipStream_t);
 
 }  // namespace npw
 
@@ -433,23 +447,30 @@ int npw_dgemm(char transA, char transB, int64_t m, int64_t n, int64_t k, double 
               const double* A, int64_t lda, const double* B, int64_t ldb, double beta,
               const double* C, int64_t ldc, double* D, int64_t ldd, const int32_t* skip_flag,
               npw_stream_t stream) {
-    return npw::gemm<double>(transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, D, ldd,
-                             skip_flag, nullptr, npw::as_stream(stream));
+    npw::GemmOpts o;
+    o.skip0 = skip_flag;
+    return npw::gemm<double>(transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, D, ldd, o,
+                             npw::as_stream(stream));
 }
 
 int npw_sgemm(char transA, char transB, int64_t m, int64_t n, int64_t k, float alpha,
               const float* A, int64_t lda, const float* B, int64_t ldb, float beta, const float* C,
               int64_t ldc, float* D, int64_t ldd, const int32_t* skip_flag, npw_stream_t stream) {
-    return npw::gemm<float>(transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, D, ldd,
-                            skip_flag, nullptr, npw::as_stream(stream));
+    npw::GemmOpts o;
+    o.skip0 = skip_flag;
+    return npw::gemm<float>(transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, D, ldd, o,
+                            npw::as_stream(stream));
 }
 
 int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t lds,
                      const double* X, int64_t ldx, const double* Y, int64_t ldy, double* D,
                      int64_t ldd, const int32_t* skip_x, const int32_t* skip_y,
                      npw_stream_t stream) {
-    return npw::gemm<double>('N', 'T', m, n, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, skip_x,
-                             skip_y, npw::as_stream(stream));
+    npw::GemmOpts o;
+    o.skip0 = skip_x;
+    o.skip1 = skip_y;
+    return npw::gemm<double>('N', 'T', m, n, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, o,
+                             npw::as_stream(stream));
 }
 
 }  // extern "C"

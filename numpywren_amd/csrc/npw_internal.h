@@ -42,10 +42,17 @@ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- internal (C++) entry points used across translation units -------------------------
 
-// D = alpha * op(A) op(B) + beta * C  with two optional skip flags (either set => no product)
+struct GemmOpts {
+    const int32_t* skip0 = nullptr;  // device flags: either one set => the product is skipped
+    const int32_t* skip1 = nullptr;
+    bool lower_only = false;  // only output tiles touching the lower triangle are computed/written
+    bool inplace_a = false;   // D aliases A (row panel update, n <= 128): forces one tile column
+};
+
+// D = alpha * op(A) op(B) + beta * C
 template <typename T>
 int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A,
          int64_t lda, const T* B, int64_t ldb, T beta, const T* C, int64_t ldc, T* D, int64_t ldd,
-         const int32_t* skip0, const int32_t* skip1, hipStream_t stream);
+         const GemmOpts& opts, hipStream_t stream);
 
 }  // namespace npw

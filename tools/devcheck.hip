@@ -101,6 +101,87 @@ static double check_gemm(char ta, char tb, int m, int n, int k, int pad) {
     return maxerr;
 }
 
+// host reference Cholesky (lower), returns false if not PD
+static bool host_chol(int n, std::vector<double>& a) {
+    for (int j = 0; j < n; ++j) {
+        double d = a[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) d -= a[(size_t)j * n + k] * a[(size_t)j * n + k];
+        if (!(d > 0)) return false;
+        d = std::sqrt(d);
+        a[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double s = a[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k) s -= a[(size_t)i * n + k] * a[(size_t)j * n + k];
+            a[(size_t)i * n + j] = s / d;
+        }
+        for (int k = j + 1; k < n; ++k) a[(size_t)j * n + k] = 0;
+    }
+    return true;
+}
+
+static int check_factor(int n, int m) {
+    // SPD matrix A = G G^T + n I
+    std::vector<double> G((size_t)n * n), A((size_t)n * n), L((size_t)n * n), B((size_t)m * n), X((size_t)m * n);
+    for (auto& x : G) x = urand();
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = 0;
+            for (int k = 0; k < n; ++k) s += G[(size_t)i * n + k] * G[(size_t)j * n + k];
+            if (i == j) s += n;
+            A[(size_t)i * n + j] = A[(size_t)j * n + i] = s;
+        }
+    for (auto& x : B) x = urand();
+    double *dA, *dL, *dB, *dX;
+    void *wsp, *wst;
+    int32_t* dinfo;
+    CK(npw_malloc((void**)&dA, A.size() * 8));
+    CK(npw_malloc((void**)&dL, A.size() * 8));
+    CK(npw_malloc((void**)&dB, B.size() * 8));
+    CK(npw_malloc((void**)&dX, B.size() * 8));
+    CK(npw_malloc(&wsp, npw_dpotrf_lower_workspace_bytes(n)));
+    CK(npw_malloc(&wst, npw_dtrsm_rltn_workspace_bytes(m, n)));
+    CK(npw_malloc((void**)&dinfo, 4));
+    CK(npw_memcpy_h2d_async(dA, A.data(), A.size() * 8, 0));
+    CK(npw_memcpy_h2d_async(dB, B.data(), B.size() * 8, 0));
+    CK(npw_dpotrf_lower(n, dA, n, dL, n, dinfo, wsp, 0));
+    CK(npw_dtrsm_rltn(m, n, dL, n, dB, n, dX, n, wst, 0));
+    int32_t info = -1;
+    CK(npw_memcpy_d2h_async(L.data(), dL, L.size() * 8, 0));
+    CK(npw_memcpy_d2h_async(X.data(), dX, X.size() * 8, 0));
+    CK(npw_memcpy_d2h_async(&info, dinfo, 4, 0));
+    CK(npw_device_synchronize());
+    std::vector<double> Lref = A;
+    bool pd = host_chol(n, Lref);
+    double el = 0, lmax = 0;
+    for (size_t i = 0; i < L.size(); ++i) {
+        el = std::fmax(el, std::fabs(L[i] - Lref[i]));
+        lmax = std::fmax(lmax, std::fabs(Lref[i]));
+    }
+    // trsm residual: X L^T = B
+    double et = 0;
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < n; ++j) {
+            double s = 0;
+            for (int k = 0; k <= j; ++k) s += X[(size_t)i * n + k] * Lref[(size_t)j * n + k];
+            et = std::fmax(et, std::fabs(s - B[(size_t)i * n + j]));
+        }
+    bool ok = pd && info == 0 && el < 1e-12 * lmax * n && et < 1e-11 * n;
+    printf("factor n=%d m=%d: info=%d |L-Lref|max=%.3e (|L|max %.2e)  trsm resid=%.3e %s\n", n, m, info, el, lmax, et,
+           ok ? "ok" : "BAD");
+    // non-PD detection: flip a diagonal entry
+    A[(size_t)(n / 2) * n + n / 2] = -1.0;
+    CK(npw_memcpy_h2d_async(dA, A.data(), A.size() * 8, 0));
+    CK(npw_dpotrf_lower(n, dA, n, dL, n, dinfo, wsp, 0));
+    CK(npw_memcpy_d2h_async(&info, dinfo, 4, 0));
+    CK(npw_device_synchronize());
+    if (info != n / 2 + 1) {
+        printf("  non-PD detection BAD: info=%d expected %d\n", info, n / 2 + 1);
+        ok = false;
+    }
+    npw_free(dA); npw_free(dL); npw_free(dB); npw_free(dX); npw_free(wsp); npw_free(wst); npw_free(dinfo);
+    return ok ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
     int ndev = 0;
     CK(npw_device_count(&ndev));
@@ -127,6 +208,12 @@ int main(int argc, char** argv) {
                 printf("gemm %c%c m=%d n=%d k=%d pad=%d  err64=%.3e err32=%.3e %s\n", tr[a], tr[b], sh.m,
                        sh.n, sh.k, sh.pad, e64, e32, ok ? "ok" : "BAD");
             }
+    {
+        int ns[] = {1, 8, 37, 128, 129, 200, 256, 300, 640, 1024};
+        for (int n : ns) bad += check_factor(n, n);
+        bad += check_factor(200, 77);
+        bad += check_factor(513, 1000);
+    }
     printf("correctness: %s (%d bad)\n", bad ? "FAILED" : "PASSED", bad);
 
     // ---- MFMA issue-rate microbenchmarks ---------------------------------------------------
@@ -189,6 +276,47 @@ int main(int argc, char** argv) {
             CK(npw_event_elapsed_ms(e0, e1, &ms));
             ms /= reps;
             printf("dgemm %s n=%d: %.3f ms  %.2f TFLOP/s\n", names[v], n, ms, 2.0 * n * n * (double)n / ms / 1e9);
+        }
+        {   // potrf / trsm at tile size: A = S S^T/n + n*I built on device
+            CK(npw_dgemm('N', 'T', n, n, n, 1.0 / n, S, n, S, n, 0.0, nullptr, n, D, n, nullptr, 0));
+            CK(npw_add_diag(D, n, n, n, (double)n, 0));
+            void *wsp, *wst;
+            int32_t* dinfo;
+            CK(npw_malloc(&wsp, npw_dpotrf_lower_workspace_bytes(n)));
+            CK(npw_malloc(&wst, npw_dtrsm_rltn_workspace_bytes(n, n)));
+            CK(npw_malloc((void**)&dinfo, 4));
+            for (int w = 0; w < 2; ++w) CK(npw_dpotrf_lower(n, D, n, X, n, dinfo, wsp, 0));
+            const int reps = 5;
+            CK(npw_event_record(e0, 0));
+            for (int r = 0; r < reps; ++r) CK(npw_dpotrf_lower(n, D, n, X, n, dinfo, wsp, 0));
+            CK(npw_event_record(e1, 0));
+            CK(npw_event_synchronize(e1));
+            float ms;
+            CK(npw_event_elapsed_ms(e0, e1, &ms));
+            ms /= reps;
+            int32_t info;
+            CK(npw_memcpy_d2h_async(&info, dinfo, 4, 0));
+            CK(npw_device_synchronize());
+            printf("dpotrf n=%d: %.3f ms  %.2f TFLOP/s (n^3/3)  info=%d\n", n, ms, n * (double)n * n / 3 / ms / 1e9, info);
+            for (int w = 0; w < 2; ++w) CK(npw_dtrsm_rltn(n, n, X, n, S, n, Y, n, wst, 0));
+            CK(npw_event_record(e0, 0));
+            for (int r = 0; r < reps; ++r) CK(npw_dtrsm_rltn(n, n, X, n, S, n, Y, n, wst, 0));
+            CK(npw_event_record(e1, 0));
+            CK(npw_event_synchronize(e1));
+            CK(npw_event_elapsed_ms(e0, e1, &ms));
+            ms /= reps;
+            printf("dtrsm n=%d: %.3f ms  %.2f TFLOP/s (n^3)\n", n, ms, n * (double)n * n / ms / 1e9);
+            // residual check at size: ||Y L^T - S||_F / ||S||_F
+            double* dsum;
+            CK(npw_malloc((void**)&dsum, 16));
+            CK(npw_dgemm('N', 'T', n, n, n, 1.0, Y, n, X, n, -1.0, S, n, D, n, nullptr, 0));
+            CK(npw_dsumsq(D, n, n, n, dsum, 0));
+            CK(npw_dsumsq(S, n, n, n, dsum + 1, 0));
+            double hs[2];
+            CK(npw_memcpy_d2h_async(hs, dsum, 16, 0));
+            CK(npw_device_synchronize());
+            printf("trsm residual at n=%d: %.3e\n", n, std::sqrt(hs[0] / hs[1]));
+            CK(npw_fill_random(Y, n, n, n, 3, 0, 0, 0));
         }
         float *Xf = (float*)X, *Yf = (float*)Y, *Df = (float*)D;
         CK(npw_convert(n, n, S, n, 0, Xf, n, 1, 0));
