@@ -182,6 +182,84 @@ static int check_factor(int n, int m) {
     return ok ? 0 : 1;
 }
 
+// host Householder QR (LAPACK dgeqr2 + dlarft conventions), row-major
+static void host_qr(int m, int n, const std::vector<double>& A, std::vector<double>& V, std::vector<double>& T,
+                    std::vector<double>& R) {
+    std::vector<double> W = A;
+    std::vector<double> tau(n);
+    for (int c = 0; c < n; ++c) {
+        double ss = 0;
+        for (int r = c + 1; r < m; ++r) ss += W[(size_t)r * n + c] * W[(size_t)r * n + c];
+        double alpha = W[(size_t)c * n + c], beta = alpha, t = 0, scale = 0;
+        if (ss != 0) {
+            double nrm = std::sqrt(alpha * alpha + ss);
+            beta = alpha >= 0 ? -nrm : nrm;
+            t = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        for (int r = c + 1; r < m; ++r) W[(size_t)r * n + c] *= scale;
+        W[(size_t)c * n + c] = beta;
+        tau[c] = t;
+        for (int k = c + 1; k < n; ++k) {
+            double d = W[(size_t)c * n + k];
+            for (int r = c + 1; r < m; ++r) d += W[(size_t)r * n + c] * W[(size_t)r * n + k];
+            W[(size_t)c * n + k] -= t * d;
+            for (int r = c + 1; r < m; ++r) W[(size_t)r * n + k] -= t * d * W[(size_t)r * n + c];
+        }
+    }
+    V.assign((size_t)m * n, 0);
+    R.assign((size_t)n * n, 0);
+    T.assign((size_t)n * n, 0);
+    for (int r = 0; r < m; ++r)
+        for (int c = 0; c < n; ++c) {
+            if (r > c) V[(size_t)r * n + c] = W[(size_t)r * n + c];
+            else if (r == c) V[(size_t)r * n + c] = 1;
+            if (r <= c && r < n) R[(size_t)r * n + c] = W[(size_t)r * n + c];
+        }
+    for (int c = 0; c < n; ++c) {
+        std::vector<double> z(c);
+        for (int k = 0; k < c; ++k) {
+            double d = 0;
+            for (int r = 0; r < m; ++r) d += V[(size_t)r * n + k] * V[(size_t)r * n + c];
+            z[k] = d;
+        }
+        for (int t = 0; t < c; ++t) {
+            double sacc = 0;
+            for (int q = t; q < c; ++q) sacc += T[(size_t)t * n + q] * z[q];
+            T[(size_t)t * n + c] = -tau[c] * sacc;
+        }
+        T[(size_t)c * n + c] = tau[c];
+    }
+}
+
+static int check_qr(int m, int n) {
+    std::vector<double> A((size_t)m * n), V, T, R, Vd((size_t)m * n), Td((size_t)n * n), Rd((size_t)n * n);
+    for (auto& x : A) x = urand();
+    host_qr(m, n, A, V, T, R);
+    double *dA, *dV, *dT, *dR;
+    void* ws;
+    CK(npw_malloc((void**)&dA, A.size() * 8));
+    CK(npw_malloc((void**)&dV, A.size() * 8));
+    CK(npw_malloc((void**)&dT, Td.size() * 8));
+    CK(npw_malloc((void**)&dR, Rd.size() * 8));
+    CK(npw_malloc(&ws, npw_dgeqrt_workspace_bytes(m, n)));
+    CK(npw_memcpy_h2d_async(dA, A.data(), A.size() * 8, 0));
+    CK(npw_dgeqrt(m, n, dA, n, dV, n, dT, n, dR, n, ws, 0));
+    CK(npw_memcpy_d2h_async(Vd.data(), dV, Vd.size() * 8, 0));
+    CK(npw_memcpy_d2h_async(Td.data(), dT, Td.size() * 8, 0));
+    CK(npw_memcpy_d2h_async(Rd.data(), dR, Rd.size() * 8, 0));
+    CK(npw_device_synchronize());
+    double ev = 0, et = 0, er = 0;
+    for (size_t i = 0; i < V.size(); ++i) ev = std::fmax(ev, std::fabs(V[i] - Vd[i]));
+    for (size_t i = 0; i < T.size(); ++i) et = std::fmax(et, std::fabs(T[i] - Td[i]));
+    for (size_t i = 0; i < R.size(); ++i) er = std::fmax(er, std::fabs(R[i] - Rd[i]));
+    const double tol = 1e-12 * (m + n);
+    bool ok = ev < tol && et < tol && er < tol * std::sqrt((double)m);
+    printf("geqrt m=%d n=%d: |dV|=%.3e |dT|=%.3e |dR|=%.3e %s\n", m, n, ev, et, er, ok ? "ok" : "BAD");
+    npw_free(dA); npw_free(dV); npw_free(dT); npw_free(dR); npw_free(ws);
+    return ok ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
     int ndev = 0;
     CK(npw_device_count(&ndev));
@@ -213,6 +291,8 @@ int main(int argc, char** argv) {
         for (int n : ns) bad += check_factor(n, n);
         bad += check_factor(200, 77);
         bad += check_factor(513, 1000);
+        int qs[][2] = {{1, 1}, {8, 8}, {16, 8}, {64, 32}, {100, 37}, {64, 64}, {256, 128}, {300, 300}, {512, 256}, {1024, 200}};
+        for (auto& q : qs) bad += check_qr(q[0], q[1]);
     }
     printf("correctness: %s (%d bad)\n", bad ? "FAILED" : "PASSED", bad);
 
@@ -317,6 +397,34 @@ int main(int argc, char** argv) {
             CK(npw_device_synchronize());
             printf("trsm residual at n=%d: %.3e\n", n, std::sqrt(hs[0] / hs[1]));
             CK(npw_fill_random(Y, n, n, n, 3, 0, 0, 0));
+        }
+        {   // QR of one tile and of a stacked pair
+            double *V2, *T2;
+            void* ws;
+            CK(npw_malloc((void**)&V2, 2 * bytes));
+            CK(npw_malloc((void**)&T2, bytes));
+            CK(npw_malloc(&ws, npw_dgeqrt_workspace_bytes(2 * n, n)));
+            for (int mm = n; mm <= 2 * n; mm += n) {
+                // input: rows of S (and Y for the stacked case) -- use X as R output
+                double* In = V2;  // reuse: copy S into a 2n x n buffer D2
+                double* D2;
+                CK(npw_malloc((void**)&D2, 2 * bytes));
+                CK(npw_memcpy_d2d_async(D2, S, bytes, 0));
+                CK(npw_memcpy_d2d_async(D2 + (size_t)n * n, Y, bytes, 0));
+                (void)In;
+                CK(npw_dgeqrt(mm, n, D2, n, V2, n, T2, n, X, n, ws, 0));
+                CK(npw_event_record(e0, 0));
+                CK(npw_dgeqrt(mm, n, D2, n, V2, n, T2, n, X, n, ws, 0));
+                CK(npw_event_record(e1, 0));
+                CK(npw_event_synchronize(e1));
+                float ms;
+                CK(npw_event_elapsed_ms(e0, e1, &ms));
+                printf("dgeqrt m=%d n=%d: %.3f ms  %.2f TFLOP/s (2mn^2-2n^3/3)\n", mm, n, ms,
+                       (2.0 * mm * n * (double)n - 2.0 * n * (double)n * n / 3) / ms / 1e9);
+                npw_free(D2);
+            }
+            npw_free(V2); npw_free(T2); npw_free(ws);
+            CK(npw_fill_random(X, n, n, n, 2, 0, 0, 0));
         }
         float *Xf = (float*)X, *Yf = (float*)Y, *Df = (float*)D;
         CK(npw_convert(n, n, S, n, 0, Xf, n, 1, 0));
