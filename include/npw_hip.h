@@ -173,6 +173,18 @@ int npw_add_diag(double* A, int64_t rows, int64_t cols, int64_t lda, double lamb
 int npw_is_zero(const double* A, int64_t rows, int64_t cols, int64_t lda, double atol,
                 int32_t* flag_dev, npw_stream_t stream);
 
+/* A[:] = 0 iff *flag_dev != 0 (device-side select, no host round trip): implements
+ * kernels.trsm's `if np.allclose(y, 0): return np.zeros(...)` (reference
+ * numpywren/kernels.py:255-256) on the asynchronous path.                     */
+int npw_zero_if(double* A, int64_t rows, int64_t cols, int64_t lda, const int32_t* flag_dev,
+                npw_stream_t stream);
+
+/* D = alpha * X + beta * Y (rows x cols, fp64).  D may alias X or Y exactly.
+ * The elementwise part of qr_leaf / lq_leaf / *_trailing_update (S0 - W, S1 - V W;
+ * reference numpywren/kernels.py:154-164,181-208).                            */
+int npw_daxpby(int64_t rows, int64_t cols, double alpha, const double* X, int64_t ldx, double beta,
+               const double* Y, int64_t ldy, double* D, int64_t ldd, npw_stream_t stream);
+
 /* B = A^T (A rows x cols, B cols x rows).  No aliasing.  Replaces the per-tile
  * `.T` of BigMatrixView (reference numpywren/matrix.py:646-647,658-659).      */
 int npw_dtranspose(int64_t rows, int64_t cols, const double* A, int64_t lda, double* B,

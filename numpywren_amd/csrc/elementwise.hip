@@ -86,6 +86,26 @@ __global__ void is_zero_kernel(const double* A, int64_t rows, int64_t cols, int6
     }
 }
 
+__global__ void zero_if_kernel(double* A, int64_t rows, int64_t cols, int64_t lda, const int32_t* flag) {
+    if (*flag == 0) return;
+    const int64_t total = rows * cols;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / cols, c = idx - r * cols;
+        A[r * lda + c] = 0.0;
+    }
+}
+
+__global__ void axpby_kernel(int64_t rows, int64_t cols, double alpha, const double* X, int64_t ldx,
+                             double beta, const double* Y, int64_t ldy, double* D, int64_t ldd) {
+    const int64_t total = rows * cols;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / cols, c = idx - r * cols;
+        D[r * ldd + c] = alpha * X[r * ldx + c] + beta * Y[r * ldy + c];
+    }
+}
+
 __global__ void transpose_kernel(int64_t rows, int64_t cols, const double* A, int64_t lda, double* B,
                                  int64_t ldb) {
     __shared__ double tile[32][33];
@@ -257,6 +277,26 @@ int npw_is_zero(const double* A, int64_t rows, int64_t cols, int64_t lda, double
     NPW_REQUIRE(A != nullptr && lda >= cols, "npw_is_zero: bad arguments");
     hipLaunchKernelGGL(is_zero_kernel, dim3(grid_for(rows * cols)), dim3(kThreads), 0, s, A, rows, cols,
                        lda, atol, flag_dev);
+    NPW_LAUNCH_CHECK();
+    return NPW_OK;
+}
+
+int npw_zero_if(double* A, int64_t rows, int64_t cols, int64_t lda, const int32_t* flag_dev,
+                npw_stream_t stream) {
+    if (rows <= 0 || cols <= 0) return NPW_OK;
+    NPW_REQUIRE(A != nullptr && flag_dev != nullptr && lda >= cols, "npw_zero_if: bad arguments");
+    hipLaunchKernelGGL(zero_if_kernel, dim3(grid_for(rows * cols)), dim3(kThreads), 0, as_stream(stream), A,
+                       rows, cols, lda, flag_dev);
+    NPW_LAUNCH_CHECK();
+    return NPW_OK;
+}
+
+int npw_daxpby(int64_t rows, int64_t cols, double alpha, const double* X, int64_t ldx, double beta,
+               const double* Y, int64_t ldy, double* D, int64_t ldd, npw_stream_t stream) {
+    if (rows <= 0 || cols <= 0) return NPW_OK;
+    NPW_REQUIRE(X && Y && D && ldx >= cols && ldy >= cols && ldd >= cols, "npw_daxpby: bad arguments");
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(rows * cols)), dim3(kThreads), 0, as_stream(stream), rows,
+                       cols, alpha, X, ldx, beta, Y, ldy, D, ldd);
     NPW_LAUNCH_CHECK();
     return NPW_OK;
 }

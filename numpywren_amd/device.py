@@ -1,0 +1,696 @@
+"""HIP backend: device tiles in HBM, a caching allocator, streams/events and typed wrappers over
+the C-ABI kernels of libnpw_hip.so.
+
+This is the substrate that replaces the reference's S3 object store + pywren workers: a
+`DeviceTile` is the HBM-resident counterpart of one `.npy` shard object (reference
+numpywren/matrix.py:519-533), `HipBackend` streams are the local worker pool (reference
+numpywren/job_runner.py:316-370).
+
+Stream ordering contract: every DeviceTile carries the event `ready` recorded on the stream
+that last wrote it; consumers on another stream wait for that event on the device (no host
+synchronisation).  Buffers return to the pool only after every stream that touched them has
+passed the release point (events recorded at release time), so asynchronous kernels never see
+recycled memory.
+"""
+import ctypes
+import os
+import threading
+import weakref
+
+import numpy as np
+
+from . import _ffi
+from .exceptions import HipExtensionError
+
+_F64 = np.dtype(np.float64)
+_F32 = np.dtype(np.float32)
+
+
+def _round_up(n, m):
+    return (n + m - 1) // m * m
+
+
+class Stream(object):
+    __slots__ = ("handle", "high_priority", "name")
+
+    def __init__(self, handle, high_priority=False, name=""):
+        self.handle = handle  # int (hipStream_t) or None for the null stream
+        self.high_priority = high_priority
+        self.name = name
+
+    def __repr__(self):
+        return f"Stream({self.name or self.handle})"
+
+
+class DeviceBuffer(object):
+    """A raw HBM allocation owned by the backend's pool; returned to the pool when garbage collected."""
+    __slots__ = ("ptr", "nbytes", "_backend", "streams", "__weakref__")
+
+    def __init__(self, backend, ptr, nbytes):
+        self.ptr = ptr
+        self.nbytes = nbytes
+        self._backend = backend
+        self.streams = set()  # handles of the streams that accessed this buffer
+
+    def __del__(self):
+        be = self._backend
+        if be is not None and self.ptr:
+            try:
+                be._release(self.ptr, self.nbytes, self.streams)
+            except Exception:
+                pass
+            self.ptr = 0
+
+
+class DeviceTile(object):
+    """One tile resident in HBM: a C-contiguous array of `shape`/`dtype` inside a DeviceBuffer."""
+    __slots__ = ("buf", "shape", "dtype", "ready", "zero_flag", "shared", "__weakref__")
+
+    def __init__(self, buf, shape, dtype):
+        self.buf = buf
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.ready = None       # (event_handle, stream_handle) of the producing kernel
+        self.zero_flag = None   # DeviceBuffer holding the cached np.allclose(tile, 0) flag (int32)
+        self.shared = False     # True for cached constant tiles that must never be written in place
+
+    @property
+    def ptr(self):
+        return self.buf.ptr
+
+    @property
+    def nbytes(self):
+        return int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    def rows_cols(self):
+        """2-D view (rows, cols) of the tile: leading dims collapse into rows."""
+        if len(self.shape) == 0:
+            return 1, 1
+        if len(self.shape) == 1:
+            return 1, self.shape[0]
+        return int(np.prod(self.shape[:-1], dtype=np.int64)), self.shape[-1]
+
+    def reshaped(self, shape):
+        """A second handle on the same buffer with a different (same-size) shape."""
+        shape = tuple(int(s) for s in shape)
+        assert int(np.prod(shape, dtype=np.int64)) == self.size, (shape, self.shape)
+        t = DeviceTile(self.buf, shape, self.dtype)
+        t.ready = self.ready
+        t.zero_flag = self.zero_flag
+        t.shared = self.shared
+        return t
+
+    def __repr__(self):
+        return f"DeviceTile(shape={self.shape}, dtype={self.dtype}, ptr=0x{self.ptr:x})"
+
+
+class HipBackend(object):
+    """One per process and device.  Thread-safe for concurrent kernel submission."""
+
+    def __init__(self, device=None, num_streams=4):
+        self.lib = _ffi.lib()
+        n = ctypes.c_int(0)
+        rc = self.lib.npw_device_count(ctypes.byref(n))
+        if rc != 0 or n.value < 1:
+            raise HipExtensionError(
+                "no HIP device visible (npw_device_count -> %d devices): numpywren_amd needs an MI355X "
+                "(gfx950); there is no CPU fallback" % n.value)
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) % n.value
+        self.device = device
+        _ffi.check(self.lib.npw_set_device(device), "npw_set_device")
+        name = ctypes.create_string_buffer(128)
+        mem = ctypes.c_size_t(0)
+        cus = ctypes.c_int(0)
+        khz = ctypes.c_int(0)
+        _ffi.check(self.lib.npw_device_info(device, name, 128, ctypes.byref(mem), ctypes.byref(cus), ctypes.byref(khz)))
+        self.arch = name.value.decode()
+        self.total_mem = mem.value
+        self.compute_units = cus.value
+        self.clock_khz = khz.value
+        self._lock = threading.RLock()
+        self._free = {}      # nbytes -> [ptr]
+        self._pending = []   # (ptr, nbytes, [event handles])
+        self._event_pool = []
+        self.allocated_bytes = 0
+        self.pooled_bytes = 0
+        self.peak_bytes = 0
+        self.default_stream = self.create_stream(name="default")
+        self.streams = [self.default_stream]
+        for i in range(1, max(1, num_streams)):
+            self.streams.append(self.create_stream(name=f"s{i}"))
+        self.priority_stream = self.create_stream(high_priority=True, name="prio")
+        self._zero_tiles = {}
+        self._tls = threading.local()
+
+    # ------------------------------------------------------------------ device / threads
+    def bind_thread(self):
+        """HIP's current device is per host thread: call once in every worker thread."""
+        if getattr(self._tls, "bound", False):
+            return
+        _ffi.check(self.lib.npw_set_device(self.device), "npw_set_device")
+        self._tls.bound = True
+
+    def mem_info(self):
+        f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        _ffi.check(self.lib.npw_mem_info(ctypes.byref(f), ctypes.byref(t)))
+        return f.value, t.value
+
+    # ------------------------------------------------------------------ streams / events
+    def create_stream(self, high_priority=False, name=""):
+        h = ctypes.c_void_p(0)
+        _ffi.check(self.lib.npw_stream_create(ctypes.byref(h), 1 if high_priority else 0), "npw_stream_create")
+        return Stream(h.value, high_priority, name)
+
+    def _sh(self, stream):
+        if stream is None:
+            return self.default_stream.handle
+        if isinstance(stream, Stream):
+            return stream.handle
+        return stream
+
+    def new_event(self, timing=False):
+        if not timing:
+            with self._lock:
+                if self._event_pool:
+                    return self._event_pool.pop()
+        h = ctypes.c_void_p(0)
+        _ffi.check(self.lib.npw_event_create(ctypes.byref(h), 1 if timing else 0), "npw_event_create")
+        return h.value
+
+    def recycle_event(self, ev):
+        with self._lock:
+            self._event_pool.append(ev)
+
+    def record(self, ev, stream=None):
+        _ffi.check(self.lib.npw_event_record(ev, self._sh(stream)), "npw_event_record")
+
+    def record_new(self, stream=None):
+        ev = self.new_event()
+        self.record(ev, stream)
+        return ev
+
+    def wait_event(self, stream, ev):
+        _ffi.check(self.lib.npw_stream_wait_event(self._sh(stream), ev), "npw_stream_wait_event")
+
+    def event_done(self, ev):
+        d = ctypes.c_int(0)
+        _ffi.check(self.lib.npw_event_query(ev, ctypes.byref(d)))
+        return bool(d.value)
+
+    def event_sync(self, ev):
+        _ffi.check(self.lib.npw_event_synchronize(ev), "npw_event_synchronize")
+
+    def elapsed_ms(self, ev0, ev1):
+        ms = ctypes.c_float(0)
+        _ffi.check(self.lib.npw_event_elapsed_ms(ev0, ev1, ctypes.byref(ms)), "npw_event_elapsed_ms")
+        return ms.value
+
+    def stream_sync(self, stream=None):
+        _ffi.check(self.lib.npw_stream_synchronize(self._sh(stream)), "npw_stream_synchronize")
+
+    def synchronize(self):
+        _ffi.check(self.lib.npw_device_synchronize(), "npw_device_synchronize")
+
+    # ------------------------------------------------------------------ allocator
+    def _alloc_raw(self, nbytes):
+        nbytes = max(256, _round_up(int(nbytes), 256))
+        with self._lock:
+            lst = self._free.get(nbytes)
+            if lst:
+                self.pooled_bytes -= nbytes
+                return lst.pop(), nbytes
+            if self._pending:
+                self._drain_pending()
+                lst = self._free.get(nbytes)
+                if lst:
+                    self.pooled_bytes -= nbytes
+                    return lst.pop(), nbytes
+        p = ctypes.c_void_p(0)
+        rc = self.lib.npw_malloc(ctypes.byref(p), nbytes)
+        if rc != 0:
+            # out of memory: give everything cached back to the driver and retry once
+            self.synchronize()
+            self.trim()
+            _ffi.check(self.lib.npw_malloc(ctypes.byref(p), nbytes), f"npw_malloc({nbytes})")
+        with self._lock:
+            self.allocated_bytes += nbytes
+            self.peak_bytes = max(self.peak_bytes, self.allocated_bytes)
+        return p.value, nbytes
+
+    def _drain_pending(self):
+        still = []
+        for ptr, nbytes, events in self._pending:
+            if all(self.event_done(e) for e in events):
+                for e in events:
+                    self._event_pool.append(e)
+                self._free.setdefault(nbytes, []).append(ptr)
+                self.pooled_bytes += nbytes
+            else:
+                still.append((ptr, nbytes, events))
+        self._pending = still
+
+    def _release(self, ptr, nbytes, streams):
+        events = []
+        for sh in streams:
+            ev = self.new_event()
+            _ffi.check(self.lib.npw_event_record(ev, sh))
+            events.append(ev)
+        with self._lock:
+            if events:
+                self._pending.append((ptr, nbytes, events))
+            else:
+                self._free.setdefault(nbytes, []).append(ptr)
+                self.pooled_bytes += nbytes
+
+    def trim(self):
+        """Return all cached (unused) buffers to the driver."""
+        with self._lock:
+            self._drain_pending()
+            for nbytes, lst in self._free.items():
+                for ptr in lst:
+                    self.lib.npw_free(ptr)
+                    self.allocated_bytes -= nbytes
+            self._free = {}
+            self.pooled_bytes = 0
+
+    def alloc(self, nbytes):
+        ptr, real = self._alloc_raw(nbytes)
+        return DeviceBuffer(self, ptr, real)
+
+    def empty(self, shape, dtype=np.float64):
+        dtype = np.dtype(dtype)
+        shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        return DeviceTile(self.alloc(nbytes), shape, dtype)
+
+    # ------------------------------------------------------------------ ordering helpers
+    def _use(self, stream, *tiles):
+        """Make `stream` wait for the producers of `tiles` and note the access for safe recycling."""
+        sh = self._sh(stream)
+        for t in tiles:
+            if t is None:
+                continue
+            if t.ready is not None and t.ready[1] != sh:
+                self.wait_event(sh, t.ready[0])
+            t.buf.streams.add(sh)
+            if t.zero_flag is not None:
+                t.zero_flag.streams.add(sh)
+
+    def _produced(self, stream, *tiles):
+        sh = self._sh(stream)
+        ev = self.record_new(sh)
+        for t in tiles:
+            t.ready = (ev, sh)
+            t.buf.streams.add(sh)
+            t.zero_flag = None
+        return ev
+
+    def wait_tile(self, tile):
+        """Host-side wait until the tile's contents are final."""
+        if tile.ready is not None:
+            self.event_sync(tile.ready[0])
+
+    # ------------------------------------------------------------------ transfers
+    def to_device(self, array, stream=None, dtype=None):
+        a = np.ascontiguousarray(array, dtype=dtype)
+        t = self.empty(a.shape, a.dtype)
+        sh = self._sh(stream)
+        if a.nbytes:
+            _ffi.check(self.lib.npw_memcpy_h2d_async(t.ptr, a.ctypes.data, a.nbytes, sh), "h2d")
+        self._produced(sh, t)
+        return t
+
+    def to_host(self, tile, stream=None, out=None):
+        sh = self._sh(stream)
+        self._use(sh, tile)
+        if out is None:
+            out = np.empty(tile.shape, dtype=tile.dtype)
+        else:
+            assert out.flags["C_CONTIGUOUS"] and out.nbytes == tile.nbytes
+        if tile.nbytes:
+            _ffi.check(self.lib.npw_memcpy_d2h_async(out.ctypes.data, tile.ptr, tile.nbytes, sh), "d2h")
+        self.stream_sync(sh)
+        return out
+
+    def copy(self, tile, stream=None):
+        sh = self._sh(stream)
+        self._use(sh, tile)
+        out = self.empty(tile.shape, tile.dtype)
+        if tile.nbytes:
+            _ffi.check(self.lib.npw_memcpy_d2d_async(out.ptr, tile.ptr, tile.nbytes, sh), "d2d")
+        self._produced(sh, out)
+        return out
+
+    def zeros(self, shape, dtype=np.float64, stream=None):
+        sh = self._sh(stream)
+        t = self.empty(shape, dtype)
+        if t.nbytes:
+            _ffi.check(self.lib.npw_memset_async(t.ptr, 0, t.nbytes, sh), "memset")
+        self._produced(sh, t)
+        return t
+
+    def shared_zeros(self, shape, dtype=np.float64):
+        """A cached read-only all-zero tile (what a `parent_fn=constant_zeros` read materialises)."""
+        key = (tuple(int(s) for s in shape), np.dtype(dtype).str)
+        with self._lock:
+            t = self._zero_tiles.get(key)
+        if t is None:
+            t = self.zeros(shape, dtype, self.default_stream)
+            t.shared = True
+            flag = self.alloc(4)
+            one = np.ones(1, dtype=np.int32)
+            _ffi.check(self.lib.npw_memcpy_h2d_async(flag.ptr, one.ctypes.data, 4, self.default_stream.handle))
+            flag.streams.add(self.default_stream.handle)
+            self.stream_sync(self.default_stream)
+            t.ready = None
+            t.zero_flag = flag
+            with self._lock:
+                self._zero_tiles[key] = t
+        return t
+
+    # ------------------------------------------------------------------ kernels on DeviceTiles
+    @staticmethod
+    def _require_2d(t, what):
+        if t.ndim != 2:
+            raise ValueError(f"{what}: expected a 2-D tile, got shape {t.shape}")
+
+    def as_f64(self, tile, stream=None):
+        if tile.dtype == _F64:
+            return tile
+        return self.convert(tile, _F64, stream)
+
+    def convert(self, tile, dtype, stream=None):
+        dtype = np.dtype(dtype)
+        if dtype == tile.dtype:
+            return tile
+        codes = {_F64: 0, _F32: 1}
+        if tile.dtype not in codes or dtype not in codes:
+            raise TypeError(f"convert: unsupported dtypes {tile.dtype} -> {dtype}")
+        sh = self._sh(stream)
+        self._use(sh, tile)
+        r, c = tile.rows_cols()
+        out = self.empty(tile.shape, dtype)
+        _ffi.check(self.lib.npw_convert(r, c, tile.ptr, c, codes[tile.dtype], out.ptr, c, codes[dtype], sh), "convert")
+        self._produced(sh, out)
+        return out
+
+    def zero_flag(self, tile, stream=None, atol=1e-8):
+        """Device int32 flag == np.allclose(tile, 0); computed once per tile version and cached."""
+        if tile.zero_flag is not None:
+            return tile.zero_flag
+        sh = self._sh(stream)
+        t64 = self.as_f64(tile, sh)
+        self._use(sh, t64)
+        flag = self.alloc(4)
+        flag.streams.add(sh)
+        r, c = t64.rows_cols()
+        _ffi.check(self.lib.npw_is_zero(t64.ptr, r, c, c, atol, flag.ptr, sh), "is_zero")
+        # the flag is only ever consumed on streams that also wait for the tile; give the tile an
+        # event that covers the flag kernel when it ran on a different stream than the producer
+        if tile.ready is None or tile.ready[1] != sh:
+            ev = self.record_new(sh)
+            tile.ready = (ev, sh)
+        tile.zero_flag = flag
+        return flag
+
+    def read_flag(self, flag, stream=None):
+        sh = self._sh(stream)
+        out = np.zeros(1, dtype=np.int32)
+        _ffi.check(self.lib.npw_memcpy_d2h_async(out.ctypes.data, flag.ptr, 4, sh))
+        self.stream_sync(sh)
+        return int(out[0])
+
+    def gemm(self, A, B, transpose_A=False, transpose_B=False, stream=None, alpha=1.0, beta=0.0, C=None, out=None,
+             skip=None):
+        """alpha * op(A) op(B) + beta * C -> new tile (or `out`).  fp64 or fp32 (both operands same dtype)."""
+        self._require_2d(A, "gemm")
+        self._require_2d(B, "gemm")
+        if A.dtype != B.dtype:
+            A, B = self.as_f64(A, stream), self.as_f64(B, stream)
+        dt = A.dtype
+        if dt not in (_F64, _F32):
+            raise TypeError(f"gemm: unsupported dtype {dt}")
+        m, ka = (A.shape[1], A.shape[0]) if transpose_A else A.shape
+        kb, n = (B.shape[1], B.shape[0]) if transpose_B else B.shape
+        if ka != kb:
+            raise ValueError(f"shapes {A.shape}{'.T' if transpose_A else ''} and {B.shape}{'.T' if transpose_B else ''} "
+                             f"not aligned: {ka} (dim 1) != {kb} (dim 0)")
+        sh = self._sh(stream)
+        if out is None:
+            out = self.empty((m, n), dt)
+        if C is not None and C.dtype != dt:
+            C = self.convert(C, dt, sh)
+        self._use(sh, A, B, C, out)
+        fn = self.lib.npw_dgemm if dt == _F64 else self.lib.npw_sgemm
+        _ffi.check(fn(b"T" if transpose_A else b"N", b"T" if transpose_B else b"N", m, n, ka, alpha, A.ptr, A.shape[1],
+                      B.ptr, B.shape[1], beta, C.ptr if C is not None else None, n, out.ptr, n,
+                      skip.ptr if skip is not None else None, sh), "gemm")
+        if skip is not None:
+            skip.streams.add(sh)
+        self._produced(sh, out)
+        return out
+
+    def syrk(self, S, X, Y, stream=None, inplace=False, exact_zero=True):
+        """S - X Y^T (kernels.syrk).  inplace=True overwrites S's buffer (caller guarantees S is dead)."""
+        for t, nm in ((S, "s"), (X, "x"), (Y, "y")):
+            self._require_2d(t, f"syrk({nm})")
+        sh = self._sh(stream)
+        S, X, Y = self.as_f64(S, sh), self.as_f64(X, sh), self.as_f64(Y, sh)
+        m, k = X.shape
+        n, k2 = Y.shape
+        if k != k2 or S.shape != (m, n):
+            raise ValueError(f"syrk: operands could not be broadcast together: s{S.shape} x{X.shape} y{Y.shape}")
+        fx = fy = None
+        if exact_zero:
+            fx = self.zero_flag(X, sh)
+            fy = fx if Y is X else self.zero_flag(Y, sh)
+        out = S if (inplace and not S.shared) else self.empty((m, n), _F64)
+        self._use(sh, S, X, Y, out)
+        _ffi.check(self.lib.npw_dgemm_nt_sub(m, n, k, S.ptr, n, X.ptr, k, Y.ptr, k, out.ptr, n,
+                                             fx.ptr if fx is not None else None, fy.ptr if fy is not None else None,
+                                             sh), "syrk")
+        self._produced(sh, out)
+        return out
+
+    def trsm(self, L, Y, stream=None, exact_zero=True):
+        """Y L^-T (kernels.trsm with x = L lower triangular)."""
+        self._require_2d(L, "trsm(x)")
+        self._require_2d(Y, "trsm(y)")
+        sh = self._sh(stream)
+        L, Y = self.as_f64(L, sh), self.as_f64(Y, sh)
+        n = L.shape[0]
+        if L.shape[1] != n or Y.shape[1] != n:
+            raise ValueError(f"trsm: incompatible shapes x{L.shape} y{Y.shape}")
+        m = Y.shape[0]
+        out = self.empty((m, n), _F64)
+        ws = self.alloc(max(16, self.lib.npw_dtrsm_rltn_workspace_bytes(m, n)))
+        ws.streams.add(sh)
+        self._use(sh, L, Y, out)
+        _ffi.check(self.lib.npw_dtrsm_rltn(m, n, L.ptr, n, Y.ptr, n, out.ptr, n, ws.ptr, sh), "trsm")
+        if exact_zero:
+            # reference: `if np.allclose(y, 0): return np.zeros(...)` -- a device-side select
+            fy = self.zero_flag(Y, sh)
+            fy.streams.add(sh)
+            _ffi.check(self.lib.npw_zero_if(out.ptr, m, n, n, fy.ptr, sh), "zero_if")
+        self._produced(sh, out)
+        return out
+
+    def chol(self, A, stream=None, info_out=None):
+        """Lower Cholesky factor (kernels.chol).  Returns (L, info_buffer); info is a device int32."""
+        self._require_2d(A, "chol")
+        sh = self._sh(stream)
+        A = self.as_f64(A, sh)
+        n = A.shape[0]
+        if A.shape[1] != n:
+            raise np.linalg.LinAlgError("Last 2 dimensions of the array must be square")
+        out = self.empty((n, n), _F64)
+        info = self.alloc(4)
+        info.streams.add(sh)
+        ws = self.alloc(max(16, self.lib.npw_dpotrf_lower_workspace_bytes(n)))
+        ws.streams.add(sh)
+        self._use(sh, A, out)
+        _ffi.check(self.lib.npw_dpotrf_lower(n, A.ptr, n, out.ptr, n, info.ptr, ws.ptr, sh), "chol")
+        self._produced(sh, out)
+        return out, info
+
+    def add_n(self, tiles, stream=None):
+        """Left-to-right sum into fp64 (kernels.add_matrices: np.zeros(shape) += a)."""
+        sh = self._sh(stream)
+        shape = tiles[0].shape
+        for t in tiles:
+            if t.shape != shape:
+                raise ValueError(f"operands could not be broadcast together with shapes {shape} {t.shape}")
+            if t.dtype not in (_F64, _F32):
+                raise TypeError(f"add_matrices: unsupported dtype {t.dtype}")
+        r, c = tiles[0].rows_cols()
+        out = self.empty(shape, _F64)
+        self._use(sh, out, *tiles)
+        n = len(tiles)
+        ptrs = (ctypes.c_void_p * n)(*[t.ptr for t in tiles])
+        lds = (ctypes.c_int64 * n)(*[c] * n)
+        isf = (ctypes.c_int32 * n)(*[1 if t.dtype == _F32 else 0 for t in tiles])
+        _ffi.check(self.lib.npw_add_n(n, ptrs, lds, isf, r, c, out.ptr, c, sh), "add_n")
+        self._produced(sh, out)
+        return out
+
+    def add_diag(self, tile, lam, stream=None):
+        """New tile = tile + lam * I (the BigMatrix `lambdav` shift applied on read)."""
+        sh = self._sh(stream)
+        out = self.copy(self.as_f64(tile, sh), sh)
+        r, c = out.rows_cols()
+        _ffi.check(self.lib.npw_add_diag(out.ptr, r, c, c, float(lam), sh), "add_diag")
+        self._produced(sh, out)
+        return out
+
+    def transpose(self, tile, stream=None):
+        self._require_2d(tile, "transpose")
+        sh = self._sh(stream)
+        if tile.dtype != _F64:
+            t64 = self.as_f64(tile, sh)
+            return self.convert(self.transpose(t64, sh), tile.dtype, sh)
+        r, c = tile.shape
+        out = self.empty((c, r), _F64)
+        self._use(sh, tile, out)
+        _ffi.check(self.lib.npw_dtranspose(r, c, tile.ptr, c, out.ptr, r, sh), "transpose")
+        self._produced(sh, out)
+        return out
+
+    def vstack(self, tiles, stream=None):
+        """np.vstack of 2-D fp64 tiles with equal column counts (rows are contiguous: plain copies)."""
+        sh = self._sh(stream)
+        tiles = [self.as_f64(t, sh) for t in tiles]
+        if len(tiles) == 1:
+            return tiles[0]
+        c = tiles[0].shape[1]
+        for t in tiles:
+            self._require_2d(t, "vstack")
+            if t.shape[1] != c:
+                raise ValueError("all the input array dimensions except for the concatenation axis must match exactly")
+        out = self.empty((sum(t.shape[0] for t in tiles), c), _F64)
+        self._use(sh, out, *tiles)
+        off = 0
+        for t in tiles:
+            _ffi.check(self.lib.npw_memcpy_d2d_async(out.ptr + off, t.ptr, t.nbytes, sh), "vstack")
+            off += t.nbytes
+        self._produced(sh, out)
+        return out
+
+    def rows(self, tile, start, stop, stream=None):
+        """tile[start:stop, :] as a new tile (contiguous rows)."""
+        self._require_2d(tile, "rows")
+        sh = self._sh(stream)
+        c = tile.shape[1]
+        out = self.empty((stop - start, c), tile.dtype)
+        self._use(sh, tile, out)
+        isz = tile.dtype.itemsize
+        if out.nbytes:
+            _ffi.check(self.lib.npw_memcpy_d2d_async(out.ptr, tile.ptr + start * c * isz, out.nbytes, sh), "rows")
+        self._produced(sh, out)
+        return out
+
+    def geqrt(self, A, stream=None):
+        """Householder QR of the m x n tile (m >= n): returns (V m x n, T n x n, R n x n)."""
+        self._require_2d(A, "qr_factor")
+        sh = self._sh(stream)
+        A = self.as_f64(A, sh)
+        m, n = A.shape
+        if m < n:
+            raise NotImplementedError(
+                f"qr_factor of a {m} x {n} block (more columns than rows) is not supported by the HIP path; the "
+                "reference routes this case to slow_qr (numpywren/kernels.py:94-95) which no algorithm uses")
+        V = self.empty((m, n), _F64)
+        T = self.empty((n, n), _F64)
+        R = self.empty((n, n), _F64)
+        ws = self.alloc(max(16, self.lib.npw_dgeqrt_workspace_bytes(m, n)))
+        ws.streams.add(sh)
+        self._use(sh, A, V, T, R)
+        _ffi.check(self.lib.npw_dgeqrt(m, n, A.ptr, n, V.ptr, n, T.ptr, n, R.ptr, n, ws.ptr, sh), "geqrt")
+        self._produced(sh, V, T, R)
+        return V, T, R
+
+    def axpby(self, alpha, X, beta, Y, stream=None):
+        """alpha * X + beta * Y for same-shape fp64 tiles (used for S0 - W style updates)."""
+        sh = self._sh(stream)
+        X, Y = self.as_f64(X, sh), self.as_f64(Y, sh)
+        if X.shape != Y.shape:
+            raise ValueError(f"operands could not be broadcast together with shapes {X.shape} {Y.shape}")
+        r, c = X.rows_cols()
+        out = self.empty(X.shape, _F64)
+        self._use(sh, X, Y, out)
+        _ffi.check(self.lib.npw_daxpby(r, c, float(alpha), X.ptr, c, float(beta), Y.ptr, c, out.ptr, c, sh), "axpby")
+        self._produced(sh, out)
+        return out
+
+    def fill_random(self, shape, seed, row0=0, col0=0, stream=None):
+        sh = self._sh(stream)
+        out = self.empty(shape, _F64)
+        r, c = out.rows_cols()
+        self._use(sh, out)
+        _ffi.check(self.lib.npw_fill_random(out.ptr, r, c, c, int(seed), int(row0), int(col0), sh), "fill_random")
+        self._produced(sh, out)
+        return out
+
+    def fill_outer(self, shape, xvec, row0, col0, lam=0.0, stream=None):
+        sh = self._sh(stream)
+        out = self.empty(shape, _F64)
+        r, c = out.rows_cols()
+        self._use(sh, out, xvec)
+        _ffi.check(self.lib.npw_fill_outer(out.ptr, r, c, c, xvec.ptr, int(row0), int(col0), float(lam), sh), "fill_outer")
+        self._produced(sh, out)
+        return out
+
+    def sumsq(self, tile, stream=None):
+        sh = self._sh(stream)
+        t = self.as_f64(tile, sh)
+        r, c = t.rows_cols()
+        acc = self.alloc(8)
+        acc.streams.add(sh)
+        self._use(sh, t)
+        _ffi.check(self.lib.npw_dsumsq(t.ptr, r, c, c, acc.ptr, sh), "sumsq")
+        out = np.zeros(1)
+        _ffi.check(self.lib.npw_memcpy_d2h_async(out.ctypes.data, acc.ptr, 8, sh))
+        self.stream_sync(sh)
+        return float(out[0])
+
+
+_backend = None
+_backend_lock = threading.Lock()
+_override = None
+
+
+def get_backend():
+    """The process-wide HipBackend (created on first use).  Raises HipExtensionError without a GPU."""
+    global _backend
+    if _override is not None:
+        return _override
+    if _backend is None:
+        with _backend_lock:
+            if _backend is None:
+                from . import config
+                _backend = HipBackend(num_streams=config.default()["executor"]["streams"])
+    return _backend
+
+
+def set_backend(backend):
+    """Install a backend object (used by the CPU-side scheduler tests to inject a checker backend)."""
+    global _override
+    _override = backend
+
+
+def hip_available():
+    """True iff the extension loads and at least one HIP device is visible (never raises)."""
+    try:
+        lib = _ffi.lib()
+        n = ctypes.c_int(0)
+        return lib.npw_device_count(ctypes.byref(n)) == 0 and n.value > 0
+    except Exception:
+        return False

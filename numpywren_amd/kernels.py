@@ -1,0 +1,366 @@
+"""Tile kernels with the reference's names, arity, kwargs and `.flops` models
+(reference numpywren/kernels.py), executed by hand-written HIP kernels on the MI355X.
+
+Calling convention (the "kernel seam"):
+  * ndarray arguments  -> H2D, HIP kernels on the default stream, D2H: ndarray results.  This is
+    the drop-in mode the reference's RemoteCall uses (`compute(*ndarrays, **kwargs)`,
+    reference numpywren/lambdapack.py:360-381).
+  * DeviceTile arguments -> DeviceTile results, asynchronous on the calling thread's current
+    stream (`stream_scope`): the executor's fast path, no host round trips.
+Inputs are never modified.  There is no CPU arithmetic in this module: without the HIP
+extension / a GPU every kernel raises HipExtensionError.
+
+Reference quirks reproduced on purpose (SURVEY.md section 8a notes): the allclose(x, 0)
+short-circuits of syrk / trsm (device-side flags), trsm's odd zero-result shape, add_matrices'
+float64 promotion, qr_leaf's formula as written (S0 - V^T S0).
+"""
+import contextlib
+import threading
+
+import numpy as np
+
+from .device import DeviceTile, get_backend
+
+_tls = threading.local()
+
+
+@contextlib.contextmanager
+def stream_scope(stream, info_sink=None, exact_zero=True):
+    """Run kernels of this thread on `stream`; Cholesky info flags are appended to `info_sink`."""
+    prev = getattr(_tls, "ctx", None)
+    _tls.ctx = (stream, info_sink, exact_zero)
+    try:
+        yield
+    finally:
+        _tls.ctx = prev
+
+
+def _ctx():
+    c = getattr(_tls, "ctx", None)
+    return c if c is not None else (None, None, True)
+
+
+def _is_host(a):
+    return isinstance(a, np.ndarray)
+
+
+def _kernel(impl):
+    """Wrap a DeviceTile implementation `impl(be, stream, *tiles, **kw)` into the dual-mode callable."""
+
+    def wrapper(*args, **kwargs):
+        be = get_backend()
+        stream, _, _ = _ctx()
+        host_mode = any(_is_host(a) for a in args)
+        if host_mode:
+            targs = [be.to_device(np.asarray(a), stream) if _is_host(a) else a for a in args]
+        else:
+            targs = list(args)
+        res = impl(be, stream, *targs, **kwargs)
+        if not host_mode:
+            return res
+
+        def back(r):
+            return be.to_host(r, stream) if isinstance(r, DeviceTile) else r
+
+        if isinstance(res, tuple):
+            return tuple(back(r) for r in res)
+        return back(res)
+
+    wrapper.__name__ = impl.__name__.lstrip("_")
+    wrapper.__doc__ = impl.__doc__
+    wrapper._npw_device_kernel = True
+    return wrapper
+
+
+def _all_f32(*tiles):
+    return all(t.dtype == np.float32 for t in tiles)
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM family
+# ------------------------------------------------------------------------------------------------
+@_kernel
+def _gemm(be, stream, A, B, *args, **kwargs):
+    """op(A) . op(B) with transpose_A / transpose_B kwargs (reference kernels.py:239-244)."""
+    return be.gemm(A, B, bool(kwargs.get("transpose_A", False)), bool(kwargs.get("transpose_B", False)), stream)
+
+
+gemm = _gemm
+
+
+def _gemm_flops(A, B):
+    m, n = A.shape
+    k = B.shape[1]
+    return 2 * m * n * k
+
+
+gemm.flops = _gemm_flops
+
+
+@_kernel
+def _syrk(be, stream, s, x, y, *args, **kwargs):
+    """s - x . y^T; returns s itself when x or y is allclose to 0 (reference kernels.py:212-215)."""
+    exact = _ctx()[2]
+    out = be.syrk(s, x, y, stream, inplace=False, exact_zero=exact)
+    if _all_f32(s, x, y):
+        out = be.convert(out, np.float32, stream)
+    return out
+
+
+syrk = _syrk
+
+
+def _syrk_flops(s, x, y):
+    m = x.shape[0]
+    n = x.shape[1]
+    z = y.shape[1]
+    return 2 * m * n * z + m * z
+
+
+syrk.flops = _syrk_flops
+
+
+@_kernel
+def _trsm(be, stream, x, y, lower=False, right=True, *args, **kwargs):
+    """Solve X . x^T = y, x lower triangular (reference kernels.py:254-257:
+    scipy.linalg.blas.dtrsm(1.0, x.T, y, lower=False, side=1)); zeros((x.shape[1], y.shape[0])) when
+    y is allclose to 0."""
+    if lower or not right:
+        raise NotImplementedError("trsm: only the reference's defaults lower=False, right=True are implemented "
+                                  "(the only form the LambdaPACK programs use)")
+    exact = _ctx()[2]
+    out = be.trsm(x, y, stream, exact_zero=exact)
+    if exact and y.shape[0] != x.shape[1]:
+        # non-square: the reference's zero short-circuit changes the result SHAPE, which needs the
+        # flag on the host
+        if be.read_flag(be.zero_flag(y, stream), stream):
+            return be.zeros((x.shape[1], y.shape[0]), np.float64, stream)
+    return out
+
+
+trsm = _trsm
+
+
+def _trsm_flops(x, y):
+    # defined by the reference but never attached (kernels.py:259-263): trsm counts 0 flops there
+    if len(y.shape) == 0:
+        return x.shape[0] * x.shape[1]
+    return x.shape[0] * x.shape[1] * y.shape[1]
+
+
+@_kernel
+def _chol(be, stream, x, *args, **kwargs):
+    """Lower Cholesky factor, upper part zero (reference kernels.py:225-226 np.linalg.cholesky);
+    raises numpy.linalg.LinAlgError for a non positive definite tile (deferred to the executor's
+    completion check on the asynchronous path)."""
+    L, info = be.chol(x, stream)
+    sink = _ctx()[1]
+    if sink is not None:
+        sink.append(info)
+    else:
+        code = be.read_flag(info, stream)
+        if code != 0:
+            raise np.linalg.LinAlgError("Matrix is not positive definite")
+    if x.dtype == np.float32:
+        L = be.convert(L, np.float32, stream)
+    return L
+
+
+chol = _chol
+
+
+def _chol_flops(x):
+    return (x.shape[0] ** 3) / 3
+
+
+chol.flops = _chol_flops
+
+
+@_kernel
+def _add_matrices(be, stream, *args, **kwargs):
+    """n-ary sum, always float64 (reference kernels.py:16-20: np.zeros(args[0].shape) += a)."""
+    return be.add_n(list(args), stream)
+
+
+add_matrices = _add_matrices
+
+
+def identity(x, *args, **kwargs):
+    """Returns its input (reference kernels.py:236-237)."""
+    return x
+
+
+identity._npw_device_kernel = True
+
+
+@_kernel
+def _mul(be, stream, x, y, *args, **kwargs):
+    """x * y for a scalar and a tile (reference kernels.py:233-234); tile * tile is not on any
+    LambdaPACK program's path."""
+    if isinstance(x, DeviceTile) and isinstance(y, DeviceTile):
+        raise NotImplementedError("mul(tile, tile) is not implemented on the HIP path")
+    if isinstance(y, DeviceTile):
+        x, y = y, x
+    return be.axpby(float(y), x, 0.0, x, stream)
+
+
+mul = _mul
+
+
+# ------------------------------------------------------------------------------------------------
+# Householder QR family
+# ------------------------------------------------------------------------------------------------
+@_kernel
+def _qr_factor(be, stream, *blocks, **kwargs):
+    """QR of vstack(blocks): (V unit-lower-trapezoid m x n, T n x n upper with Q = I - V T V^T,
+    R n x n upper) -- reference kernels.py:127-130 -> fast_qr 86-105 (LAPACK dgeqrt3)."""
+    ins = be.vstack(list(blocks), stream)
+    return be.geqrt(ins, stream)
+
+
+qr_factor = _qr_factor
+fast_qr = _qr_factor
+
+
+def _qr_flops(*blocks):
+    m = sum(b.shape[0] for b in blocks)
+    n = blocks[0].shape[1]
+    return 2 * m * n * n - (2 * n ** 3) / 3
+
+
+qr_factor.flops = _qr_flops
+
+
+@_kernel
+def _lq_factor(be, stream, *blocks, **kwargs):
+    """LQ of hstack(blocks) by transposition: fast_qr(ins.T) -> (v.T, t.T, r.T)
+    (reference kernels.py:145-150)."""
+    if len(blocks) == 2:
+        assert blocks[0].shape[0] == blocks[1].shape[0]
+    ins_t = be.vstack([be.transpose(b, stream) for b in blocks], stream)  # == hstack(blocks).T
+    V, T, R = be.geqrt(ins_t, stream)
+    return be.transpose(V, stream), be.transpose(T, stream), be.transpose(R, stream)
+
+
+lq_factor = _lq_factor
+lq_factor.flops = _qr_flops
+
+
+@_kernel
+def _qr_leaf(be, stream, V, T, S0, *args, **kwargs):
+    """S0 - V^T S0, exactly as the reference writes it (kernels.py:160-164; the WY form is commented
+    out there)."""
+    return be.gemm(V, S0, True, False, stream, alpha=-1.0, beta=1.0, C=S0)
+
+
+qr_leaf = _qr_leaf
+
+
+@_kernel
+def _lq_leaf(be, stream, V, T, S0, *args, **kwargs):
+    """S0 - S0 V^T T^T V (reference kernels.py:154-157)."""
+    a1 = be.gemm(S0, V, False, True, stream)
+    a2 = be.gemm(a1, T, False, True, stream)
+    return be.gemm(a2, V, False, False, stream, alpha=-1.0, beta=1.0, C=S0)
+
+
+lq_leaf = _lq_leaf
+
+
+def _qr_leaf_flops(V, T, S0):
+    c0 = V.shape[0] * S0.shape[0] * S0.shape[1]
+    c1 = T.shape[0] * V.shape[0] * S0.shape[1]
+    c2 = V.shape[0] * T.shape[0] * T.shape[1]
+    return c0 + c1 + c2 + S0.shape[0] * S0.shape[1]
+
+
+qr_leaf.flops = _qr_leaf_flops
+lq_leaf.flops = _qr_leaf_flops
+
+
+@_kernel
+def _qr_trailing_update(be, stream, V, T, S0, S1=None, *args, **kwargs):
+    """V = V[-S0.rows:];  W = T^T (S0 + V^T S1);  returns (S0 - W, S1 - V W)
+    (reference kernels.py:181-188)."""
+    if S1 is None:
+        return be.gemm(V, S0, True, False, stream, alpha=-1.0, beta=1.0, C=S0), be.zeros(S0.shape, np.float64, stream)
+    rows = S0.shape[0]
+    Vb = be.rows(be.as_f64(V, stream), V.shape[0] - rows, V.shape[0], stream) if V.shape[0] != rows else V
+    X = be.gemm(Vb, S1, True, False, stream, alpha=1.0, beta=1.0, C=S0)
+    W = be.gemm(T, X, True, False, stream)
+    S01 = be.axpby(1.0, S0, -1.0, W, stream)
+    S11 = be.gemm(Vb, W, False, False, stream, alpha=-1.0, beta=1.0, C=S1)
+    return S01, S11
+
+
+qr_trailing_update = _qr_trailing_update
+
+
+def _qr_trailing_flops(V, T, S0, S1):
+    M, N = V.shape
+    c0 = M * S1.shape[0] * S1.shape[1]
+    c1 = T.shape[0] * T.shape[1] * S0.shape[1]
+    return 2 * c1 + c0 + T.shape[0] * T.shape[1]
+
+
+qr_trailing_update.flops = _qr_trailing_flops
+
+
+@_kernel
+def _lq_trailing_update(be, stream, V, T, S0, S1=None, *args, **kwargs):
+    """V = V[:, -S0.rows:];  W = (S0 + S1 V^T) T^T;  returns (S0 - W, S1 - W V)
+    (reference kernels.py:199-208)."""
+    if S1 is None:
+        a1 = be.gemm(S0, V, False, True, stream)
+        a2 = be.gemm(a1, T, False, True, stream)
+        return be.gemm(a2, V, False, False, stream, alpha=-1.0, beta=1.0, C=S0), be.zeros(S0.shape, np.float64, stream)
+    cols = S0.shape[0]
+    if V.shape[1] != cols:
+        # last `cols` columns of V == (last `cols` rows of V^T)^T
+        Vt = be.transpose(be.as_f64(V, stream), stream)
+        Vr = be.transpose(be.rows(Vt, Vt.shape[0] - cols, Vt.shape[0], stream), stream)
+    else:
+        Vr = V
+    X = be.gemm(S1, Vr, False, True, stream, alpha=1.0, beta=1.0, C=S0)
+    W = be.gemm(X, T, False, True, stream)
+    S01 = be.axpby(1.0, S0, -1.0, W, stream)
+    S11 = be.gemm(W, Vr, False, False, stream, alpha=-1.0, beta=1.0, C=S1)
+    assert S0.shape == S01.shape
+    assert S1.shape == S11.shape
+    return S01, S11
+
+
+lq_trailing_update = _lq_trailing_update
+lq_trailing_update.flops = _qr_trailing_flops
+
+
+# panel kernels sit on the critical path of the factorizations and are latency-bound: the executor
+# issues them on its high-priority stream so they overtake queued trailing updates
+for _k in (chol, trsm, qr_factor, lq_factor):
+    _k._npw_latency_bound = True
+
+
+# ------------------------------------------------------------------------------------------------
+# surface kept for import compatibility; not on the gemm / cholesky / tsqr / bdfac paths
+# ------------------------------------------------------------------------------------------------
+def slow_qr(x):
+    raise NotImplementedError("slow_qr (dgeqrf + dlarft for n > m; reference kernels.py:67-84) is not used by any "
+                              "LambdaPACK program and has no HIP implementation yet")
+
+
+def fast_qr_triangular(x0, x1):
+    raise NotImplementedError("fast_qr_triangular (LAPACK dtpqrt; reference kernels.py:107-124) is the structured "
+                              "triangle-on-triangle QR of alg_wrappers.qr -- listed as 'next' in SURVEY.md 8(f)")
+
+
+def qr_factor_triangular(x0, x1, **kwargs):
+    return fast_qr_triangular(x0, x1)
+
+
+def banded_to_bidiagonal(x):
+    raise NotImplementedError("banded_to_bidiagonal (LAPACK dgbbrd; reference kernels.py:43-65) is not used by "
+                              "alg_wrappers and has no HIP implementation yet")
+
+
+def trsm_sub(L, S, x):
+    raise NotImplementedError("trsm_sub (reference kernels.py:178-179) is unused by the LambdaPACK programs")
