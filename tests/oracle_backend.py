@@ -1,0 +1,150 @@
+"""A CHECKER backend for the CPU test-suite: the HipBackend interface implemented with NumPy and
+the oracle kernels, so that the host logic above the C-ABI (BigMatrix tile paths, the compiler,
+LambdaPackProgram, the stream executor, the multi-GPU exchange schedule under gloo) can be
+exercised without a GPU.  It lives under tests/ on purpose: the product never falls back to it
+(numpywren_amd.device.get_backend raises HipExtensionError without a HIP device).
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import npw_oracle as oracle  # noqa: E402
+
+from numpywren_amd.device import DeviceTile, Stream  # noqa: E402
+
+
+class _Buf(object):
+    def __init__(self):
+        self.ptr = 0
+        self.nbytes = 0
+        self.streams = set()
+
+
+class HostTile(DeviceTile):
+    """DeviceTile look-alike holding an ndarray."""
+    __slots__ = ("array",)
+
+    def __init__(self, array):
+        array = np.array(array)
+        super().__init__(_Buf(), array.shape, array.dtype)
+        self.array = array
+
+    def reshaped(self, shape):
+        t = HostTile(self.array.reshape(shape))
+        t.shared = self.shared
+        return t
+
+
+class _Flag(object):
+    def __init__(self, v):
+        self.value = int(v)
+        self.streams = set()
+
+
+class OracleBackend(object):
+    def __init__(self, num_streams=4):
+        self.streams = [Stream(i + 1, name=f"s{i}") for i in range(num_streams)]
+        self.default_stream = self.streams[0]
+        self.priority_stream = Stream(99, True, "prio")
+        self.device = 0
+        self.calls = []
+
+    # plumbing -------------------------------------------------------------------------------
+    def bind_thread(self):
+        pass
+
+    def synchronize(self):
+        pass
+
+    def stream_sync(self, stream=None):
+        pass
+
+    def wait_tile(self, tile):
+        pass
+
+    def to_device(self, array, stream=None, dtype=None):
+        return HostTile(np.ascontiguousarray(array, dtype=dtype))
+
+    def to_host(self, tile, stream=None, out=None):
+        return np.array(tile.array)
+
+    def zeros(self, shape, dtype=np.float64, stream=None):
+        return HostTile(np.zeros(shape, dtype=dtype))
+
+    def shared_zeros(self, shape, dtype=np.float64):
+        t = HostTile(np.zeros(shape, dtype=dtype))
+        t.shared = True
+        return t
+
+    def copy(self, tile, stream=None):
+        return HostTile(tile.array)
+
+    def read_flag(self, flag, stream=None):
+        return flag.value
+
+    def zero_flag(self, tile, stream=None, atol=1e-8):
+        return _Flag(np.allclose(tile.array, 0))
+
+    def as_f64(self, tile, stream=None):
+        return tile if tile.dtype == np.float64 else HostTile(tile.array.astype(np.float64))
+
+    def convert(self, tile, dtype, stream=None):
+        return HostTile(tile.array.astype(dtype))
+
+    # kernels -----------------------------------------------------------------------------------
+    def gemm(self, A, B, transpose_A=False, transpose_B=False, stream=None, alpha=1.0, beta=0.0, C=None, out=None,
+             skip=None):
+        self.calls.append(("gemm", stream))
+        r = alpha * oracle.gemm(A.array, B.array, transpose_A=transpose_A, transpose_B=transpose_B)
+        if C is not None and beta != 0:
+            r = r + beta * C.array
+        return HostTile(r)
+
+    def syrk(self, S, X, Y, stream=None, inplace=False, exact_zero=True):
+        self.calls.append(("syrk", stream))
+        if exact_zero:
+            return HostTile(oracle.syrk(S.array, X.array, Y.array))
+        return HostTile(S.array - X.array @ Y.array.T)
+
+    def trsm(self, L, Y, stream=None, exact_zero=True):
+        self.calls.append(("trsm", stream))
+        if exact_zero and np.allclose(Y.array, 0):
+            return HostTile(np.zeros(Y.array.shape))
+        import scipy.linalg
+        return HostTile(scipy.linalg.blas.dtrsm(1.0, L.array.T, Y.array, lower=False, side=1))
+
+    def chol(self, A, stream=None, info_out=None):
+        self.calls.append(("chol", stream))
+        try:
+            return HostTile(oracle.chol(A.array)), _Flag(0)
+        except np.linalg.LinAlgError:
+            return HostTile(np.full(A.array.shape, np.nan)), _Flag(1)
+
+    def add_n(self, tiles, stream=None):
+        self.calls.append(("add_n", stream))
+        return HostTile(oracle.add_matrices(*[t.array for t in tiles]))
+
+    def add_diag(self, tile, lam, stream=None):
+        a = np.array(tile.array, dtype=np.float64)
+        a[np.diag_indices(min(a.shape))] += lam
+        return HostTile(a)
+
+    def transpose(self, tile, stream=None):
+        return HostTile(tile.array.T)
+
+    def vstack(self, tiles, stream=None):
+        return HostTile(np.vstack([t.array for t in tiles]))
+
+    def rows(self, tile, start, stop, stream=None):
+        return HostTile(tile.array[start:stop])
+
+    def geqrt(self, A, stream=None):
+        self.calls.append(("geqrt", stream))
+        v, t, r = oracle.fast_qr(A.array)
+        return HostTile(v), HostTile(t), HostTile(r)
+
+    def axpby(self, alpha, X, beta, Y, stream=None):
+        return HostTile(alpha * X.array + beta * Y.array)

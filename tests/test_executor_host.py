@@ -1,0 +1,165 @@
+"""The host side of the executor (alg_wrappers -> compiler -> LambdaPackProgram -> job_runner ->
+kernels wrappers -> BigMatrix tile paths) on CPU, with the NumPy/oracle CHECKER backend injected
+under it (tests/oracle_backend.py).  Results are compared with the whole-algorithm golden outputs
+recorded from the reference (tests/golden/algos.npz).  The same scenarios run on the real HIP backend
+in test_algorithms_gpu.py."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from numpywren_amd import alg_wrappers, job_runner
+from numpywren_amd import lambdapack as lp
+from numpywren_amd.matrix import BigMatrix
+from numpywren_amd.matrix_init import shard_matrix
+
+ALG = np.load(os.path.join(GOLDEN, "algos.npz"))
+
+
+def run(program, **kw):
+    program.start()
+    res = job_runner.lambdapack_run(program, timeout=60, idle_timeout=6, **kw)
+    program.wait()
+    program.free()
+    return res
+
+
+@pytest.mark.parametrize("tag", ["32_8", "20_8", "24_8_lam", "40_8_t2"])
+def test_cholesky(tag, oracle_backend):
+    A, L = ALG[f"cholesky_{tag}/A"], ALG[f"cholesky_{tag}/L"]
+    n, b, lam, trunc, ntasks = ALG[f"cholesky_{tag}/meta"]
+    X = BigMatrix(f"chol_in_{tag}", shape=A.shape, shard_sizes=(int(b), int(b)), write_header=True, lambdav=float(lam))
+    shard_matrix(X, A)
+    program, meta = alg_wrappers.cholesky(X, truncate=int(trunc))
+    assert meta["outputs"][0].key == f"Cholesky(chol_in_{tag})"
+    assert meta["intermediates"][0].key == f"Cholesky.Intermediate(chol_in_{tag})"
+    res = run(program)
+    assert program.program_status() == lp.PS.SUCCESS
+    assert set(res) == {"up_time", "exec_time", "executed_messages", "operator_refs", "log"}
+    assert len(res["executed_messages"]) == int(ntasks)
+    np.testing.assert_allclose(meta["outputs"][0].numpy(), L, rtol=1e-12, atol=1e-12)
+    assert program.get_progress() == int(ntasks)
+    assert program.get_flops() > 0 and program.get_read() > 0 and program.get_write() > 0
+    assert program.get_up() == 0
+
+
+def test_cholesky_streams_and_priority(oracle_backend):
+    A = ALG["cholesky_32_8/A"]
+    X = BigMatrix("chol_streams", shape=A.shape, shard_sizes=(8, 8))
+    shard_matrix(X, A)
+    program, meta = alg_wrappers.cholesky(X)
+    run(program, pipeline_width=3)
+    prio = {s for k, s in oracle_backend.calls if k in ("chol", "trsm")}
+    bulk = {s for k, s in oracle_backend.calls if k == "syrk"}
+    assert prio == {oracle_backend.priority_stream}            # panel kernels on the high-priority stream
+    assert len(bulk) == 3 and oracle_backend.priority_stream not in bulk
+
+
+def test_cholesky_not_positive_definite(oracle_backend):
+    A = -np.eye(16)
+    X = BigMatrix("chol_bad", shape=A.shape, shard_sizes=(8, 8))
+    shard_matrix(X, A)
+    program, meta = alg_wrappers.cholesky(X)
+    run(program)
+    assert program.program_status() == lp.PS.EXCEPTION
+    assert any("positive definite" in str(v) for v in program.exceptions.values())
+
+
+def test_reclaim_intermediates(oracle_backend):
+    A = ALG["cholesky_32_8/A"]
+    X = BigMatrix("chol_reclaim", shape=A.shape, shard_sizes=(8, 8))
+    shard_matrix(X, A)
+    program, meta = alg_wrappers.cholesky(X)
+    program.config["executor"]["reclaim_intermediates"] = True
+    run(program)
+    np.testing.assert_allclose(meta["outputs"][0].numpy(), ALG["cholesky_32_8/L"], rtol=1e-12, atol=1e-12)
+    assert meta["intermediates"][0].block_idxs_exist == []       # every S version died after its last reader
+    assert len(X.block_idxs_exist) == 16                           # inputs are never reclaimed
+
+
+@pytest.mark.parametrize("tag,b", [("32_8", 8), ("40_8", 8), ("16_8_f32", 8)])
+def test_gemm(tag, b, oracle_backend):
+    A, B, C = ALG[f"gemm_{tag}/A"], ALG[f"gemm_{tag}/B"], ALG[f"gemm_{tag}/C"]
+    Ab = BigMatrix(f"gemm_A_{tag}", shape=A.shape, shard_sizes=(b, b), dtype=A.dtype)
+    Bb = BigMatrix(f"gemm_B_{tag}", shape=B.shape, shard_sizes=(b, b), dtype=B.dtype)
+    shard_matrix(Ab, A)
+    shard_matrix(Bb, B)
+    program, meta = alg_wrappers.gemm(Ab, Bb)
+    run(program, pipeline_width=3)
+    assert program.program_status() == lp.PS.SUCCESS
+    got = meta["outputs"][0].numpy()
+    tol = 1e-5 if A.dtype == np.float32 else 1e-12
+    np.testing.assert_allclose(got, C, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("tag,b", [("64_8", 8), ("32_16", 16)])
+def test_tsqr(tag, b, oracle_backend):
+    Xh = ALG[f"tsqr_{tag}/X"]
+    X = BigMatrix(f"tsqr_in_{tag}", shape=Xh.shape, shard_sizes=(b, Xh.shape[1]))
+    shard_matrix(X, Xh)
+    program, meta = alg_wrappers.tsqr(X)
+    run(program)
+    assert program.program_status() == lp.PS.SUCCESS
+    R, V, T = meta["outputs"]
+    levels = int(np.log2(Xh.shape[0] // b))
+    np.testing.assert_allclose(R.get_block(levels, 0), ALG[f"tsqr_{tag}/R_final"], atol=1e-12)
+    np.testing.assert_allclose(V.get_block(levels, 0), ALG[f"tsqr_{tag}/V_top"], atol=1e-12)
+    np.testing.assert_allclose(T.get_block(0, 0), ALG[f"tsqr_{tag}/T_leaf0"], atol=1e-12)
+
+
+def test_bdfac(oracle_backend):
+    Xh = ALG["bdfac_16_4/X"]
+    X = BigMatrix("bdfac_in", shape=Xh.shape, shard_sizes=(4, 4))
+    shard_matrix(X, Xh)
+    program, meta = alg_wrappers.bdfac(X)
+    res = run(program, pipeline_width=1)
+    assert program.program_status() == lp.PS.SUCCESS
+    assert len(res["executed_messages"]) == int(ALG["bdfac_16_4/ntasks"])
+    L, R = meta["outputs"]
+    for name in ("R_0_2_0", "R_1_2_1", "R_2_1_2", "R_3_0_3"):
+        np.testing.assert_allclose(R.get_block(*[int(x) for x in name.split("_")[1:]]), ALG[f"bdfac_16_4/{name}"], atol=1e-11)
+    for name in ("L_0_2_1", "L_1_1_2", "L_2_0_3"):
+        np.testing.assert_allclose(L.get_block(*[int(x) for x in name.split("_")[1:]]), ALG[f"bdfac_16_4/{name}"], atol=1e-11)
+
+
+def test_user_python_kernel(oracle_backend):
+    """Arbitrary callables from the DSL function's scope receive ndarrays, like in the reference."""
+    from numpywren_amd import compiler
+
+    def double_it(x):
+        return 2 * x
+
+    def prog(A: BigMatrix, B: BigMatrix, N: int):
+        for i in range(N):
+            B[i, 0] = double_it(A[i, 0])
+
+    Xh = np.arange(32.0).reshape(16, 2)
+    A = BigMatrix("uk_A", shape=Xh.shape, shard_sizes=(4, 2))
+    B = BigMatrix("uk_B", shape=Xh.shape, shard_sizes=(4, 2))
+    shard_matrix(A, Xh)
+    p = compiler.lpcompile_for_execution(prog, ["A"], ["B"], kernels={"double_it": double_it})(A, B, 4)
+    program = lp.LambdaPackProgram(p, config={})
+    run(program)
+    assert program.program_status() == lp.PS.SUCCESS
+    np.testing.assert_array_equal(B.numpy(), 2 * Xh)
+
+
+def test_duplicate_and_replayed_tasks_do_not_double_count(oracle_backend):
+    """reference tests/test_job_runner.py:120-190: duplicate messages must not corrupt the run."""
+    A = ALG["cholesky_32_8/A"]
+    X = BigMatrix("chol_dup", shape=A.shape, shard_sizes=(8, 8))
+    shard_matrix(X, A)
+    program, meta = alg_wrappers.cholesky(X)
+    program.start()
+    program._enqueue((0, {}))          # a second copy of the starter
+    ex = job_runner.LambdaPackExecutor(program)
+    import asyncio
+    loop = asyncio.new_event_loop()
+    loop.run_until_complete(ex.run(0, {}))
+    loop.run_until_complete(ex.run(0, {}))   # replay of a finished node: skipped
+    loop.close()
+    program.post_op(0, {}, lp.PS.SUCCESS, None)  # replayed post_op: edges are sets, nothing double counts
+    job_runner.lambdapack_run(program, timeout=60)
+    assert program.program_status() == lp.PS.SUCCESS
+    np.testing.assert_allclose(meta["outputs"][0].numpy(), ALG["cholesky_32_8/L"], rtol=1e-12, atol=1e-12)

@@ -1,0 +1,218 @@
+"""PARITY TESTS PROPER (GPU): every numpywren_amd.kernels function, called through the C-ABI of
+libnpw_hip.so on the MI355X, against (a) the golden vectors recorded from the reference and
+(b) the oracle on seeded inputs, including the reference's edge cases (zero short-circuits, ragged
+and non-square tiles, fp32 promotion, non-PD input).
+
+Tolerances (fp64 unless stated): element-wise |got - ref| <= 1e-12 * K-scaled magnitude for GEMM-like
+kernels (different summation order than BLAS), 1e-10 relative for the factorizations; fp32 GEMM 1e-4."""
+import os
+
+import numpy as np
+import pytest
+
+import npw_oracle as oracle
+from conftest import GOLDEN
+from numpywren_amd import kernels
+
+pytestmark = pytest.mark.gpu
+KAT = np.load(os.path.join(GOLDEN, "kernels_kat.npz"))
+
+CALLS = {
+    "gemm_nn": lambda a, b: kernels.gemm(a, b), "gemm_tn": lambda a, b: kernels.gemm(a, b, transpose_A=True),
+    "gemm_nt": lambda a, b: kernels.gemm(a, b, transpose_B=True),
+    "gemm_tt": lambda a, b: kernels.gemm(a, b, transpose_A=True, transpose_B=True),
+    "gemm_f32": lambda a, b: kernels.gemm(a, b), "gemm_ragged": lambda a, b: kernels.gemm(a, b),
+    "syrk": kernels.syrk, "syrk_same": lambda s, x: kernels.syrk(s, x, x), "syrk_xzero": kernels.syrk,
+    "syrk_yzero": kernels.syrk, "syrk_ragged": kernels.syrk, "chol": kernels.chol, "trsm": kernels.trsm,
+    "trsm_yzero": kernels.trsm, "trsm_ragged": kernels.trsm, "trsm_ragged_yzero": kernels.trsm,
+    "add4": kernels.add_matrices, "add_f32": kernels.add_matrices, "identity": kernels.identity,
+    "qr_factor": kernels.qr_factor, "qr_factor_stack": kernels.qr_factor, "qr_factor_rr": kernels.qr_factor,
+    "qr_factor_tall": kernels.qr_factor, "lq_factor": kernels.lq_factor, "lq_factor_pair": kernels.lq_factor,
+    "qr_leaf": kernels.qr_leaf, "lq_leaf": kernels.lq_leaf, "qr_trailing": kernels.qr_trailing_update,
+    "lq_trailing": kernels.lq_trailing_update,
+}
+
+
+def _fn_for(case):
+    base = case
+    while base and base not in CALLS:
+        base = base.rsplit("_", 1)[0] if "_" in base else ""
+    return CALLS[base]
+
+
+ALL_CASES = sorted({k.split("/")[0] for k in KAT.files if "/" in k})
+
+
+@pytest.mark.parametrize("case", ALL_CASES)
+def test_golden_kat(case):
+    ins = []
+    i = 0
+    while f"{case}/in{i}" in KAT:
+        ins.append(KAT[f"{case}/in{i}"])
+        i += 1
+    outs = [KAT[f"{case}/out{j}"] for j in range(int(KAT[f"{case}/nout"]))]
+    keep = [a.copy() for a in ins]
+    got = _fn_for(case)(*ins)
+    got = got if isinstance(got, tuple) else (got,)
+    assert len(got) == len(outs)
+    f32 = outs[0].dtype == np.float32
+    for g, o in zip(got, outs):
+        assert g.shape == o.shape, (case, g.shape, o.shape)
+        assert g.dtype == o.dtype, (case, g.dtype, o.dtype)
+        np.testing.assert_allclose(g, o, rtol=1e-4 if f32 else 1e-10, atol=1e-4 if f32 else 1e-11)
+    for a, k in zip(ins, keep):
+        assert np.array_equal(a, k), f"{case}: kernel modified an input"
+
+
+@pytest.mark.parametrize("m,n,k", [(64, 64, 64), (128, 128, 128), (256, 192, 160), (100, 37, 19), (1, 1, 1), (130, 257, 33),
+                                   (512, 512, 512)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_vs_oracle(m, n, k, ta, tb):
+    rng = np.random.default_rng(m * 7 + n * 3 + k)
+    A = rng.standard_normal((k, m) if ta else (m, k))
+    B = rng.standard_normal((n, k) if tb else (k, n))
+    got = kernels.gemm(A, B, transpose_A=ta, transpose_B=tb)
+    ref = oracle.gemm(A, B, transpose_A=ta, transpose_B=tb)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-13 * k * 10)
+    got32 = kernels.gemm(A.astype(np.float32), B.astype(np.float32), transpose_A=ta, transpose_B=tb)
+    assert got32.dtype == np.float32
+    np.testing.assert_allclose(got32, ref, rtol=1e-3, atol=1e-5 * k)
+
+
+def test_gemm_shape_errors():
+    with pytest.raises(ValueError, match="not aligned"):
+        kernels.gemm(np.ones((4, 5)), np.ones((4, 5)))
+
+
+@pytest.mark.parametrize("b", [8, 64, 200, 256, 384])
+def test_cholesky_chain_vs_oracle(b):
+    """chol -> trsm -> syrk on one tile column, the three Cholesky task kinds."""
+    rng = np.random.default_rng(b)
+    G = rng.standard_normal((b, b))
+    A = G @ G.T + b * np.eye(b)
+    L = kernels.chol(A)
+    Lr = oracle.chol(A)
+    np.testing.assert_allclose(L, Lr, rtol=1e-10, atol=1e-10 * np.abs(Lr).max())
+    assert not np.triu(L, 1).any()
+    Y = rng.standard_normal((b, b))
+    X = kernels.trsm(L, Y)
+    np.testing.assert_allclose(X, oracle.trsm(Lr, Y), rtol=1e-9, atol=1e-10)
+    S = rng.standard_normal((b, b))
+    np.testing.assert_allclose(kernels.syrk(S, X, Y), oracle.syrk(S, X, Y), rtol=0, atol=1e-12 * b)
+
+
+def test_chol_not_positive_definite():
+    A = np.eye(40)
+    A[17, 17] = -1.0
+    with pytest.raises(np.linalg.LinAlgError):
+        kernels.chol(A)
+    A[17, 17] = np.nan
+    with pytest.raises(np.linalg.LinAlgError):
+        kernels.chol(A)
+
+
+def test_zero_short_circuits():
+    rng = np.random.default_rng(5)
+    s, x = rng.standard_normal((32, 32)), rng.standard_normal((32, 32))
+    tiny = np.full((32, 32), 9e-9)
+    assert np.array_equal(kernels.syrk(s, tiny, x), s)          # allclose(x, 0) -> s unchanged
+    assert np.array_equal(kernels.syrk(s, x, tiny), s)
+    assert not np.array_equal(kernels.syrk(s, np.full((32, 32), 2e-8), x), s)   # just above atol
+    nanx = tiny.copy()
+    nanx[3, 3] = np.nan                                                         # NaN is never allclose to 0
+    assert np.isnan(kernels.syrk(s, nanx, x)).any()
+    L = np.linalg.cholesky(np.eye(32) * 4 + 1)
+    assert not kernels.trsm(L, tiny).any()
+    z = kernels.trsm(L[:8, :8], np.zeros((5, 8)))                               # reference's odd zero shape
+    assert z.shape == (8, 5) and not z.any()
+
+
+def test_add_matrices_promotes_to_float64():
+    rng = np.random.default_rng(6)
+    a = rng.standard_normal((16, 24)).astype(np.float32)
+    b = rng.standard_normal((16, 24))
+    out = kernels.add_matrices(a, b, a)
+    assert out.dtype == np.float64
+    assert np.array_equal(out, oracle.add_matrices(a, b, a))                    # bit-exact: same left-to-right order
+    many = [rng.standard_normal((8, 8)) for _ in range(11)]
+    assert np.array_equal(kernels.add_matrices(*many), oracle.add_matrices(*many))
+
+
+@pytest.mark.parametrize("m,n", [(8, 8), (16, 8), (64, 64), (96, 32), (128, 128), (200, 67), (256, 128)])
+def test_qr_factor_vs_oracle(m, n):
+    rng = np.random.default_rng(m + n)
+    A = rng.standard_normal((m, n))
+    V, T, R = kernels.qr_factor(A)
+    Vr, Tr, Rr = oracle.qr_factor(A)
+    tol = 1e-11 * max(m, n)
+    np.testing.assert_allclose(V, Vr, atol=tol)
+    np.testing.assert_allclose(T, Tr, atol=tol)
+    np.testing.assert_allclose(R, Rr, atol=tol * 10)
+    # structure and the defining identity Q = I - V T V^T, Q[:, :n] R = A
+    assert not np.triu(V, 1).any() and np.all(np.diag(V) == 1) and not np.tril(T, -1).any() and not np.tril(R, -1).any()
+    Q = np.eye(m) - V @ T @ V.T
+    np.testing.assert_allclose(Q[:, :n] @ R, A, atol=1e-11 * m)
+    np.testing.assert_allclose(Q.T @ Q, np.eye(m), atol=1e-11 * m)
+
+
+def test_qr_family_vs_oracle():
+    rng = np.random.default_rng(9)
+    b = 48
+    A, B, S0, S1 = (rng.standard_normal((b, b)) for _ in range(4))
+    for got, ref in zip(kernels.qr_factor(A, B), oracle.qr_factor(A, B)):
+        np.testing.assert_allclose(got, ref, atol=1e-10)
+    for got, ref in zip(kernels.lq_factor(A, B), oracle.lq_factor(A, B)):
+        np.testing.assert_allclose(got, ref, atol=1e-10)
+    V, T, R = oracle.qr_factor(np.triu(A), np.triu(B))
+    for got, ref in zip(kernels.qr_trailing_update(V, T, S0, S1), oracle.qr_trailing_update(V, T, S0, S1)):
+        np.testing.assert_allclose(got, ref, atol=1e-10)
+    Vl, Tl, Ll = oracle.lq_factor(np.tril(A), np.tril(B))
+    for got, ref in zip(kernels.lq_trailing_update(Vl, Tl, S0, S1), oracle.lq_trailing_update(Vl, Tl, S0, S1)):
+        np.testing.assert_allclose(got, ref, atol=1e-10)
+    V1, T1, _ = oracle.qr_factor(A)
+    np.testing.assert_allclose(kernels.qr_leaf(V1, T1, S0), oracle.qr_leaf(V1, T1, S0), atol=1e-11)
+    Vq, Tq, _ = oracle.lq_factor(A)
+    np.testing.assert_allclose(kernels.lq_leaf(Vq, Tq, S0), oracle.lq_leaf(Vq, Tq, S0), atol=1e-10)
+    a, z = kernels.qr_trailing_update(V1, T1, S0, None)
+    np.testing.assert_allclose(a, oracle.qr_leaf(V1, T1, S0), atol=1e-11)
+    assert not z.any()
+
+
+def test_flop_models_match_reference():
+    import json
+    ref = json.loads(bytes(KAT["flops_json"]).decode())
+    a8, a16 = np.zeros((8, 8)), np.zeros((16, 8))
+    assert kernels.gemm.flops(a8, a8) == ref["gemm"]
+    assert kernels.syrk.flops(a8, a8, a8) == ref["syrk"]
+    assert kernels.chol.flops(a8) == ref["chol"]
+    assert kernels.qr_factor.flops(a8) == ref["qr_factor"]
+    assert kernels.qr_factor.flops(a8, a8) == ref["qr_factor_stack"]
+    assert kernels.qr_leaf.flops(a8, a8, a8) == ref["qr_leaf"]
+    assert kernels.qr_trailing_update.flops(a16, a8, a8, a8) == ref["qr_trailing_update"]
+    assert not hasattr(kernels.trsm, "flops")
+
+
+def test_tile_size_properties():
+    """Size-independent checks at tile sizes the oracle cannot afford in a test: residuals of the
+    4096-class kernels (linearity / round trips) computed on the device."""
+    from numpywren_amd.device import get_backend
+    be = get_backend()
+    n = 2048
+    G = be.fill_random((n, n), seed=11)
+    A = be.gemm(G, G, False, True, alpha=1.0 / n)
+    A = be.add_diag(A, 4.0)
+    L, info = be.chol(A)
+    assert be.read_flag(info) == 0
+    # || A - L L^T ||_F / || A ||_F
+    Rm = be.gemm(L, L, False, True, alpha=-1.0, beta=1.0, C=A)
+    res = np.sqrt(be.sumsq(Rm) / be.sumsq(A))
+    assert res < 1e-14, res
+    Y = be.fill_random((n, n), seed=12)
+    Xs = be.trsm(L, Y)
+    Rt = be.gemm(Xs, L, False, True, alpha=1.0, beta=-1.0, C=Y)
+    assert np.sqrt(be.sumsq(Rt) / be.sumsq(Y)) < 1e-14
+    V, T, R = be.geqrt(Y)
+    # R^T R = Y^T Y
+    YtY = be.gemm(Y, Y, True, False)
+    D = be.gemm(R, R, True, False, alpha=1.0, beta=-1.0, C=YtY)
+    assert np.sqrt(be.sumsq(D) / be.sumsq(YtY)) < 1e-13

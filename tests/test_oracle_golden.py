@@ -1,0 +1,160 @@
+"""Pin the oracle: every function of oracle/npw_oracle.py against the golden vectors produced by
+RUNNING THE REFERENCE (tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import npw_oracle as oracle
+from conftest import GOLDEN
+
+KAT = np.load(os.path.join(GOLDEN, "kernels_kat.npz"))
+ALG = np.load(os.path.join(GOLDEN, "algos.npz"))
+
+
+def _case(name):
+    ins = []
+    i = 0
+    while f"{name}/in{i}" in KAT:
+        ins.append(KAT[f"{name}/in{i}"])
+        i += 1
+    outs = [KAT[f"{name}/out{i}"] for i in range(int(KAT[f"{name}/nout"]))]
+    return ins, outs
+
+
+def _names(prefix):
+    return sorted({k.split("/")[0] for k in KAT.files if k.startswith(prefix)})
+
+
+CALLS = {
+    "gemm_nn": lambda a, b: oracle.gemm(a, b), "gemm_tn": lambda a, b: oracle.gemm(a, b, transpose_A=True),
+    "gemm_nt": lambda a, b: oracle.gemm(a, b, transpose_B=True),
+    "gemm_tt": lambda a, b: oracle.gemm(a, b, transpose_A=True, transpose_B=True),
+    "gemm_f32": lambda a, b: oracle.gemm(a, b), "gemm_ragged": lambda a, b: oracle.gemm(a, b),
+    "syrk": oracle.syrk, "syrk_same": lambda s, x: oracle.syrk(s, x, x), "syrk_xzero": oracle.syrk,
+    "syrk_yzero": oracle.syrk, "syrk_ragged": oracle.syrk, "chol": oracle.chol, "trsm": oracle.trsm,
+    "trsm_yzero": oracle.trsm, "trsm_ragged": oracle.trsm, "trsm_ragged_yzero": oracle.trsm,
+    "add4": oracle.add_matrices, "add_f32": oracle.add_matrices, "identity": oracle.identity,
+    "qr_factor": oracle.qr_factor, "qr_factor_stack": oracle.qr_factor, "qr_factor_rr": oracle.qr_factor,
+    "qr_factor_tall": oracle.qr_factor, "lq_factor": oracle.lq_factor, "lq_factor_pair": oracle.lq_factor,
+    "qr_leaf": oracle.qr_leaf, "lq_leaf": oracle.lq_leaf, "qr_trailing": oracle.qr_trailing_update,
+    "lq_trailing": oracle.lq_trailing_update,
+}
+
+
+def _fn_for(case):
+    base = case
+    while base and base not in CALLS:
+        base = base.rsplit("_", 1)[0] if "_" in base else ""
+    return CALLS[base]
+
+
+ALL_CASES = sorted({k.split("/")[0] for k in KAT.files if "/" in k})
+
+
+@pytest.mark.parametrize("case", ALL_CASES)
+def test_kernel_kat(case):
+    ins, outs = _case(case)
+    got = _fn_for(case)(*ins)
+    got = got if isinstance(got, tuple) else (got,)
+    assert len(got) == len(outs)
+    for g, o in zip(got, outs):
+        assert g.shape == o.shape, (case, g.shape, o.shape)
+        assert g.dtype == o.dtype, (case, g.dtype, o.dtype)
+        # same LAPACK/BLAS underneath: agreement to rounding
+        np.testing.assert_allclose(g, o, rtol=1e-12, atol=1e-12)
+
+
+def test_householder_restatement_matches_lapack():
+    rng = np.random.default_rng(0)
+    for m, n in ((8, 8), (16, 8), (40, 13), (64, 64)):
+        x = rng.standard_normal((m, n))
+        v0, t0, r0 = oracle.fast_qr(x)
+        v1, t1, r1 = oracle.householder_qr(x)
+        np.testing.assert_allclose(v1, v0, atol=1e-12)
+        np.testing.assert_allclose(t1, t0, atol=1e-12)
+        np.testing.assert_allclose(r1, r0, atol=1e-12)
+        q = np.eye(m) - v0 @ t0 @ v0.T
+        np.testing.assert_allclose(q[:, :n] @ r0, x, atol=1e-12)
+
+
+def test_flop_models():
+    ref = json.loads(bytes(KAT["flops_json"]).decode())
+    a8, a16 = np.zeros((8, 8)), np.zeros((16, 8))
+    assert oracle.gemm_flops(a8, a8) == ref["gemm"]
+    assert oracle.syrk_flops(a8, a8, a8) == ref["syrk"]
+    assert oracle.chol_flops(a8) == ref["chol"]
+    assert oracle.qr_flops(a8) == ref["qr_factor"]
+    assert oracle.qr_flops(a8, a8) == ref["qr_factor_stack"]
+    assert oracle.qr_leaf_flops(a8, a8, a8) == ref["qr_leaf"] == ref["lq_leaf"]
+    assert oracle.qr_trailing_flops(a16, a8, a8, a8) == ref["qr_trailing_update"] == ref["lq_trailing_update"]
+    assert ref["trsm_has_flops"] == 0.0
+
+
+@pytest.mark.parametrize("tag", ["32_8", "20_8", "24_8_lam", "40_8_t2"])
+def test_cholesky_program(tag):
+    A, L = ALG[f"cholesky_{tag}/A"], ALG[f"cholesky_{tag}/L"]
+    n, b, lam, trunc, _ = ALG[f"cholesky_{tag}/meta"]
+    got = oracle.cholesky(A, int(b), lambdav=float(lam), truncate=int(trunc))
+    np.testing.assert_allclose(got, L, rtol=1e-12, atol=1e-12)
+    if trunc == 0:
+        np.testing.assert_allclose(got, np.linalg.cholesky(A + lam * np.eye(int(n))), rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag,b", [("32_8", 8), ("40_8", 8), ("16_8_f32", 8)])
+def test_gemm_program(tag, b):
+    A, B, C = ALG[f"gemm_{tag}/A"], ALG[f"gemm_{tag}/B"], ALG[f"gemm_{tag}/C"]
+    got = oracle.gemm_program(A, B, b)
+    np.testing.assert_allclose(got, C, rtol=1e-6 if A.dtype == np.float32 else 1e-12, atol=1e-6 if A.dtype == np.float32 else 1e-12)
+
+
+@pytest.mark.parametrize("tag,b", [("64_8", 8), ("32_16", 16)])
+def test_tsqr_program(tag, b):
+    X = ALG[f"tsqr_{tag}/X"]
+    res = oracle.tsqr(X, b)
+    lv = res["levels"]
+    np.testing.assert_allclose(res["Rs"][(lv, 0)], ALG[f"tsqr_{tag}/R_final"], atol=1e-12)
+    np.testing.assert_allclose(res["Rs"][(0, 0)], ALG[f"tsqr_{tag}/R_leaf0"], atol=1e-12)
+    np.testing.assert_allclose(res["Vs"][(0, 0)], ALG[f"tsqr_{tag}/V_leaf0"], atol=1e-12)
+    np.testing.assert_allclose(res["Ts"][(0, 0)], ALG[f"tsqr_{tag}/T_leaf0"], atol=1e-12)
+    np.testing.assert_allclose(res["Vs"][(lv, 0)], ALG[f"tsqr_{tag}/V_top"], atol=1e-12)
+    np.testing.assert_allclose(res["Ts"][(lv, 0)], ALG[f"tsqr_{tag}/T_top"], atol=1e-12)
+    # the reference's own acceptance test: |R| equals numpy's R up to row signs
+    R = np.linalg.qr(X)[1]
+    np.testing.assert_allclose(np.abs(res["Rs"][(lv, 0)]), np.abs(R), atol=1e-10)
+
+
+def test_bdfac_program():
+    X = ALG["bdfac_16_4/X"]
+    R_QR, L_LQ = oracle.bdfac(X, 4)
+    for name in ("R_0_2_0", "R_1_2_1", "R_2_1_2", "R_3_0_3"):
+        idx = tuple(int(x) for x in name.split("_")[1:])
+        np.testing.assert_allclose(R_QR.get(idx), ALG[f"bdfac_16_4/{name}"], atol=1e-11)
+    for name in ("L_0_2_1", "L_1_1_2", "L_2_0_3"):
+        idx = tuple(int(x) for x in name.split("_")[1:])
+        np.testing.assert_allclose(L_LQ.get(idx), ALG[f"bdfac_16_4/{name}"], atol=1e-11)
+    # NOTE: the reference's qr_leaf as committed (kernels.py:160-164, WY form commented out) does not
+    # apply the reflector, so the assembled factor does NOT keep X's singular values -- the reference's
+    # own test_bdfac assertion cannot hold at this commit.  Parity means reproducing it as written
+    # (checked tile by tile above).  With the WY form restored the invariant holds, which validates
+    # the program structure and every other kernel:
+    fixed = dict(oracle.KERNELS)
+    fixed["qr_leaf"] = lambda V, T, S0, *a, **k: S0 - V @ T.T @ (V.T @ S0)
+    R_QR, L_LQ = oracle.bdfac(X, 4, kernels=fixed)
+    z = np.zeros((4, 4))
+    fac = np.block([[R_QR.get((0, 2, 0)), L_LQ.get((0, 2, 1)), z, z], [z, R_QR.get((1, 2, 1)), L_LQ.get((1, 1, 2)), z],
+                    [z, z, R_QR.get((2, 1, 2)), L_LQ.get((2, 0, 3))], [z, z, z, R_QR.get((3, 0, 3))]])
+    np.testing.assert_allclose(np.linalg.svd(fac, compute_uv=False), np.linalg.svd(X, compute_uv=False), atol=1e-10)
+
+
+def test_block_indexing():
+    fx = json.load(open(os.path.join(GOLDEN, "indexing.json")))
+    for c in fx["matrices"]:
+        shape, shards = tuple(c["shape"]), tuple(c["shard_sizes"])
+        for a in range(len(shape)):
+            assert [list(b) for b in oracle.blocks_axis(shape, shards, a)] == c["blocks_axis"][a]
+        for k in c["keys"] + [c["beyond"]]:
+            assert [list(x) for x in oracle.block_idx_to_real_idx(shape, shards, k["bidx"])] == k["real"]
+            key_base = k["key"].rsplit("/", 1)[0]
+            assert oracle.shard_key(key_base, shape, shards, k["bidx"]) == k["key"]
