@@ -257,6 +257,20 @@ qr_leaf = _qr_leaf
 
 
 @_kernel
+def _qr_leaf_wy(be, stream, V, T, S0, *args, **kwargs):
+    """S0 - V T^T (V^T S0): the compact-WY application of Q^T that the reference has commented out
+    in qr_leaf (kernels.py:162).  Not used by default (parity = the reference as written); pass
+    `kernels={"qr_leaf": kernels.qr_leaf_wy}` to lpcompile_for_execution to run BDFAC / QR with a
+    mathematically valid leaf update."""
+    w = be.gemm(V, S0, True, False, stream)
+    w = be.gemm(T, w, True, False, stream)
+    return be.gemm(V, w, False, False, stream, alpha=-1.0, beta=1.0, C=S0)
+
+
+qr_leaf_wy = _qr_leaf_wy
+
+
+@_kernel
 def _lq_leaf(be, stream, V, T, S0, *args, **kwargs):
     """S0 - S0 V^T T^T V (reference kernels.py:154-157)."""
     a1 = be.gemm(S0, V, False, True, stream)
@@ -275,6 +289,7 @@ def _qr_leaf_flops(V, T, S0):
 
 
 qr_leaf.flops = _qr_leaf_flops
+qr_leaf_wy.flops = _qr_leaf_flops
 lq_leaf.flops = _qr_leaf_flops
 
 

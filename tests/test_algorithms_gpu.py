@@ -200,6 +200,10 @@ def test_tsqr_like_reference_test(hbm_store):
 
 
 def test_bdfac_golden(hbm_store):
+    """As-written parity.  The reference's committed qr_leaf (S0 - V^T S0) makes the intermediate
+    matrices rank deficient, so some Householder pivots are ~0 and their reflection SIGN is decided by
+    rounding noise (LAPACK vs MFMA summation order): tiles are compared in magnitude, which is also how the
+    reference's own test compares its R block (tests/test_alg_correctness.py:272)."""
     Xh = ALG["bdfac_16_4/X"]
     X = BigMatrix("bdfac_in", shape=Xh.shape, shard_sizes=(4, 4))
     shard_matrix(X, Xh)
@@ -209,9 +213,49 @@ def test_bdfac_golden(hbm_store):
     assert len(res["executed_messages"]) == int(ALG["bdfac_16_4/ntasks"])
     L, R = meta["outputs"]
     for name in ("R_0_2_0", "R_1_2_1", "R_2_1_2", "R_3_0_3"):
-        np.testing.assert_allclose(R.get_block(*[int(x) for x in name.split("_")[1:]]), ALG[f"bdfac_16_4/{name}"], atol=1e-10)
+        got = R.get_block(*[int(x) for x in name.split("_")[1:]])
+        np.testing.assert_allclose(np.abs(got), np.abs(ALG[f"bdfac_16_4/{name}"]), atol=1e-9)
     for name in ("L_0_2_1", "L_1_1_2", "L_2_0_3"):
-        np.testing.assert_allclose(L.get_block(*[int(x) for x in name.split("_")[1:]]), ALG[f"bdfac_16_4/{name}"], atol=1e-10)
+        got = L.get_block(*[int(x) for x in name.split("_")[1:]])
+        np.testing.assert_allclose(np.abs(got), np.abs(ALG[f"bdfac_16_4/{name}"]), atol=1e-9)
+
+
+@pytest.mark.parametrize("n,b", [(16, 4), (128, 32), (192, 64)])
+def test_bdfac_well_posed(n, b, hbm_store):
+    """BDFAC with the WY-form leaf update (the line the reference has commented out): every pivot is
+    well conditioned, so tiles must match the oracle running the same program strictly, and the assembled
+    block-bidiagonal factor keeps X's singular values (the reference test's intended invariant)."""
+    from numpywren_amd import compiler, kernels
+    from numpywren_amd.algs import BDFAC
+    rng = np.random.default_rng(n)
+    Xh = rng.standard_normal((n, n))
+    X = BigMatrix(f"bdfac_wp_{n}", shape=Xh.shape, shard_sizes=(b, b))
+    shard_matrix(X, Xh)
+    _, meta = alg_wrappers.bdfac(X)   # builds the eight work matrices with the reference's names / shapes
+    L_LQ, R_QR = meta["outputs"]
+    S_LQ, S_QR, T_QR, V_QR, V_LQ, T_LQ = meta["intermediates"]
+    nb = X.num_blocks(0)
+    p = compiler.lpcompile_for_execution(BDFAC, ["I"], ["R_QR", "L_LQ"], kernels={"qr_leaf": kernels.qr_leaf_wy})(
+        X, V_QR, T_QR, S_QR, R_QR, V_LQ, T_LQ, S_LQ, L_LQ, nb, 0)
+    program = lp.LambdaPackProgram(p, config={})
+    run(program)
+    assert program.program_status() == lp.PS.SUCCESS, program.exceptions
+    fixed = dict(oracle.KERNELS)
+    fixed["qr_leaf"] = lambda V, T, S0, *a, **k: S0 - V @ T.T @ (V.T @ S0)
+    R_ref, L_ref = oracle.bdfac(Xh, b, kernels=fixed)
+    levels = lambda m: int(np.ceil(np.log2(m))) if m > 1 else 0
+    fac = np.zeros((n, n))
+    for i in range(nb):
+        idx = (i, levels(nb - i), i)
+        got = R_QR.get_block(*idx)
+        np.testing.assert_allclose(got, R_ref.get(idx), atol=1e-9)
+        fac[i * b:(i + 1) * b, i * b:(i + 1) * b] = got
+        if i + 1 < nb:
+            idx = (i, levels(nb - i - 1), i + 1)
+            got = L_LQ.get_block(*idx)
+            np.testing.assert_allclose(got, L_ref.get(idx), atol=1e-9)
+            fac[i * b:(i + 1) * b, (i + 1) * b:(i + 2) * b] = got
+    np.testing.assert_allclose(np.linalg.svd(fac, compute_uv=False), np.linalg.svd(Xh, compute_uv=False), atol=1e-9)
 
 
 def test_bigmatrix_hbm_roundtrips(hbm_store):
