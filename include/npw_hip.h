@@ -81,6 +81,10 @@ int npw_memcpy2d_d2d_async(void* dst, size_t dpitch, const void* src, size_t spi
  * Replaces the pywren worker fan-out + asyncio read/compute/write pipeline
  * (reference numpywren/job_runner.py:224-370).                                */
 int npw_stream_create(npw_stream_t* stream, int high_priority);
+/* stream whose kernels may only run on the compute units whose bit is set in cu_mask (bit i of
+ * word i/32 = CU i): used to keep a few CUs free of long-running trailing-update workgroups so
+ * the latency-bound panel kernels of the critical path always find a slot.               */
+int npw_stream_create_masked(npw_stream_t* stream, const uint32_t* cu_mask, int words);
 int npw_stream_destroy(npw_stream_t stream);
 int npw_stream_synchronize(npw_stream_t stream);
 int npw_stream_query(npw_stream_t stream, int* done);
@@ -130,6 +134,23 @@ int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t l
 size_t npw_dtrsm_rltn_workspace_bytes(int64_t m, int64_t n);
 int npw_dtrsm_rltn(int64_t m, int64_t n, const double* L, int64_t ldl, const double* B,
                    int64_t ldb, double* X, int64_t ldx, void* workspace, npw_stream_t stream);
+
+/* The same solve split in two so that the many trsm tasks of one Cholesky step, which share
+ * the same L (reference numpywren/algs.py:243-246: O[j,i] = trsm(O[i,i], S[i,j,i]) for all j),
+ * invert its diagonal blocks once:
+ *   npw_dtrtri_diag      Winv <- inverses of the 128 x 128 diagonal blocks of the n x n lower
+ *                        triangular L (block b at Winv + b*128*128, row-major, ld 128);
+ *                        Winv has npw_dtrtri_diag_bytes(n) bytes.
+ *   npw_dtrsm_rltn_inv   X = B * L^-T using those inverses; workspace:
+ *                        npw_dtrsm_rltn_inv_workspace_bytes(m, n) bytes.
+ * npw_dpotrf_lower leaves exactly such a Winv in the first npw_dtrtri_diag_bytes(n) bytes of
+ * its workspace, so a factor and its block inverses can be handed on together.            */
+size_t npw_dtrtri_diag_bytes(int64_t n);
+int npw_dtrtri_diag(int64_t n, const double* L, int64_t ldl, double* Winv, npw_stream_t stream);
+size_t npw_dtrsm_rltn_inv_workspace_bytes(int64_t m, int64_t n);
+int npw_dtrsm_rltn_inv(int64_t m, int64_t n, const double* L, int64_t ldl, const double* Winv,
+                       const double* B, int64_t ldb, double* X, int64_t ldx, void* workspace,
+                       npw_stream_t stream);
 
 /* Cholesky factor of the n x n SPD matrix A (only its lower triangle is read):
  * Lout = lower triangular L with A = L L^T, strictly-upper part of Lout set to 0.

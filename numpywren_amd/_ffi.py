@@ -46,6 +46,7 @@ PROTOTYPES = {
     "npw_memcpy2d_d2h_async": (c_int, [_vp, _sz, _vp, _sz, _sz, _sz, _vp]),
     "npw_memcpy2d_d2d_async": (c_int, [_vp, _sz, _vp, _sz, _sz, _sz, _vp]),
     "npw_stream_create": (c_int, [POINTER(_vp), c_int]),
+    "npw_stream_create_masked": (c_int, [POINTER(_vp), POINTER(ctypes.c_uint32), c_int]),
     "npw_stream_destroy": (c_int, [_vp]),
     "npw_stream_synchronize": (c_int, [_vp]),
     "npw_stream_query": (c_int, [_vp, POINTER(c_int)]),
@@ -64,6 +65,10 @@ PROTOTYPES = {
     "npw_dgemm_nt_sub": (c_int, [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "npw_dtrsm_rltn_workspace_bytes": (_sz, [_i64, _i64]),
     "npw_dtrsm_rltn": (c_int, [_i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "npw_dtrtri_diag_bytes": (_sz, [_i64]),
+    "npw_dtrtri_diag": (c_int, [_i64, _vp, _i64, _vp, _vp]),
+    "npw_dtrsm_rltn_inv_workspace_bytes": (_sz, [_i64, _i64]),
+    "npw_dtrsm_rltn_inv": (c_int, [_i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "npw_dpotrf_lower_workspace_bytes": (_sz, [_i64]),
     "npw_dpotrf_lower": (c_int, [_i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "npw_dgeqrt_workspace_bytes": (_sz, [_i64, _i64]),

@@ -8,7 +8,11 @@ import os
 DEFAULTS = {
     "executor": {
         "streams": 4,            # HIP streams in the worker pool (job_runner pipeline_width analogue)
-        "priority_stream": True,  # one high-priority stream for the critical path
+        # Issue the latency-bound panel kernels (chol / trsm / qr_factor) on a separate high-priority
+        # stream.  Off by default: measured on MI355X (profiles/r01_overlap_study.md) a resident
+        # 1024-workgroup trailing update leaves no free slot (LDS-full CUs, no preemption), so every
+        # small panel kernel queues ~1 ms behind it and the critical path gets slower, not faster.
+        "priority_stream": False,
         "exact_zero_shortcircuit": True,  # reproduce the reference's allclose(x, 0) early-outs
         "reclaim_intermediates": False,   # free intermediate tiles after their last reader
     },

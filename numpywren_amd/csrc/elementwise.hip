@@ -19,6 +19,23 @@ inline int grid_for(int64_t work_items) {
     return (int)b;
 }
 
+// 2-D launch shape for row-major rows x cols sweeps: x covers the columns (coalesced), y strides over
+// rows -- no per-element integer division (a 64-bit divide costs far more than the 8-byte access).
+inline dim3 grid2d(int64_t rows, int64_t cols) {
+    int64_t gx = ceil_div(cols, kThreads);
+    if (gx > 64) gx = 64;
+    int64_t gy = kMaxBlocks * 2 / gx;
+    if (gy > rows) gy = rows;
+    if (gy < 1) gy = 1;
+    if (gy > 65535) gy = 65535;
+    return dim3((unsigned)gx, (unsigned)gy);
+}
+
+#define NPW_FOR_2D(r, c, rows, cols)                                                       \
+    for (int64_t r = blockIdx.y; r < (rows); r += gridDim.y)                                \
+        for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < (cols);        \
+             c += (int64_t)gridDim.x * blockDim.x)
+
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
 // ---- add_n -------------------------------------------------------------------------------
@@ -32,10 +49,7 @@ struct AddArgs {
 
 __global__ void add_n_kernel(AddArgs a, int64_t rows, int64_t cols, double* out, int64_t ld_out,
                              bool accumulate) {
-    const int64_t total = rows * cols;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = idx / cols, c = idx - r * cols;
+    NPW_FOR_2D(r, c, rows, cols) {
         // the reference accumulates left to right into zeros: ((0 + a0) + a1) + ...
         double s = accumulate ? out[r * ld_out + c] : 0.0;
 #pragma unroll
@@ -72,11 +86,8 @@ __global__ void init_flag_kernel(int32_t* flag, int32_t v) { *flag = v; }
 
 __global__ void is_zero_kernel(const double* A, int64_t rows, int64_t cols, int64_t lda, double atol,
                                int32_t* flag) {
-    const int64_t total = rows * cols;
     bool bad = false;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = idx / cols, c = idx - r * cols;
+    NPW_FOR_2D(r, c, rows, cols) {
         const double v = A[r * lda + c];
         // np.allclose(v, 0): |v - 0| <= atol + rtol*|0|, and non-finite values never match
         if (!(fabs(v) <= atol)) bad = true;
@@ -88,20 +99,14 @@ __global__ void is_zero_kernel(const double* A, int64_t rows, int64_t cols, int6
 
 __global__ void zero_if_kernel(double* A, int64_t rows, int64_t cols, int64_t lda, const int32_t* flag) {
     if (*flag == 0) return;
-    const int64_t total = rows * cols;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = idx / cols, c = idx - r * cols;
+    NPW_FOR_2D(r, c, rows, cols) {
         A[r * lda + c] = 0.0;
     }
 }
 
 __global__ void axpby_kernel(int64_t rows, int64_t cols, double alpha, const double* X, int64_t ldx,
                              double beta, const double* Y, int64_t ldy, double* D, int64_t ldd) {
-    const int64_t total = rows * cols;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = idx / cols, c = idx - r * cols;
+    NPW_FOR_2D(r, c, rows, cols) {
         D[r * ldd + c] = alpha * X[r * ldx + c] + beta * Y[r * ldy + c];
     }
 }
@@ -128,10 +133,7 @@ __global__ void transpose_kernel(int64_t rows, int64_t cols, const double* A, in
 
 __global__ void tri_keep_kernel(bool lower, bool unit, int64_t rows, int64_t cols, double* A,
                                 int64_t lda) {
-    const int64_t total = rows * cols;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = idx / cols, c = idx - r * cols;
+    NPW_FOR_2D(r, c, rows, cols) {
         if (r == c) {
             if (unit) A[r * lda + c] = 1.0;
         } else if (lower ? (c > r) : (c < r)) {
@@ -143,20 +145,14 @@ __global__ void tri_keep_kernel(bool lower, bool unit, int64_t rows, int64_t col
 template <typename S, typename D>
 __global__ void convert_kernel(int64_t rows, int64_t cols, const S* src, int64_t lds, D* dst,
                                int64_t ldd) {
-    const int64_t total = rows * cols;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = idx / cols, c = idx - r * cols;
+    NPW_FOR_2D(r, c, rows, cols) {
         dst[r * ldd + c] = (D)src[r * lds + c];
     }
 }
 
 __global__ void fill_outer_kernel(double* A, int64_t rows, int64_t cols, int64_t lda, const double* x,
                                   int64_t row0, int64_t col0, double lambda) {
-    const int64_t total = rows * cols;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = idx / cols, c = idx - r * cols;
+    NPW_FOR_2D(r, c, rows, cols) {
         double v = x[row0 + r] * x[col0 + c];
         if (row0 + r == col0 + c) v += lambda;
         A[r * lda + c] = v;
@@ -174,10 +170,7 @@ __device__ inline uint64_t splitmix64(uint64_t z) {
 // (seed, global row, global col), so any tiling of the same matrix gives the same numbers.
 __global__ void fill_random_kernel(double* A, int64_t rows, int64_t cols, int64_t lda, uint64_t seed,
                                    int64_t row0, int64_t col0) {
-    const int64_t total = rows * cols;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = idx / cols, c = idx - r * cols;
+    NPW_FOR_2D(r, c, rows, cols) {
         const uint64_t key = splitmix64(seed ^ splitmix64((uint64_t)(row0 + r) * 0x100000001B3ULL + (uint64_t)(col0 + c)));
         const uint64_t k2 = splitmix64(key);
         const double u1 = ((double)(key >> 11) + 1.0) * (1.0 / 9007199254740993.0);
@@ -187,11 +180,8 @@ __global__ void fill_random_kernel(double* A, int64_t rows, int64_t cols, int64_
 }
 
 __global__ void sumsq_kernel(const double* A, int64_t rows, int64_t cols, int64_t lda, double* out) {
-    const int64_t total = rows * cols;
     double s = 0;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = idx / cols, c = idx - r * cols;
+    NPW_FOR_2D(r, c, rows, cols) {
         const double v = A[r * lda + c];
         s += v * v;
     }
@@ -247,7 +237,7 @@ int npw_add_n(int count, const void* const* in, const int64_t* ld_in, const int3
             hipLaunchKernelGGL(add_n_vec_kernel, dim3(grid_for(total2)), dim3(kThreads), 0, s, a, total2,
                                reinterpret_cast<d2_t*>(out), base > 0);
         } else {
-            hipLaunchKernelGGL(add_n_kernel, dim3(grid_for(rows * cols)), dim3(kThreads), 0, s, a, rows,
+            hipLaunchKernelGGL(add_n_kernel, grid2d(rows, cols), dim3(kThreads), 0, s, a, rows,
                                cols, out, ld_out, base > 0);
         }
         NPW_LAUNCH_CHECK();
@@ -275,7 +265,7 @@ int npw_is_zero(const double* A, int64_t rows, int64_t cols, int64_t lda, double
     NPW_LAUNCH_CHECK();
     if (rows * cols == 0) return NPW_OK;
     NPW_REQUIRE(A != nullptr && lda >= cols, "npw_is_zero: bad arguments");
-    hipLaunchKernelGGL(is_zero_kernel, dim3(grid_for(rows * cols)), dim3(kThreads), 0, s, A, rows, cols,
+    hipLaunchKernelGGL(is_zero_kernel, grid2d(rows, cols), dim3(kThreads), 0, s, A, rows, cols,
                        lda, atol, flag_dev);
     NPW_LAUNCH_CHECK();
     return NPW_OK;
@@ -285,7 +275,7 @@ int npw_zero_if(double* A, int64_t rows, int64_t cols, int64_t lda, const int32_
                 npw_stream_t stream) {
     if (rows <= 0 || cols <= 0) return NPW_OK;
     NPW_REQUIRE(A != nullptr && flag_dev != nullptr && lda >= cols, "npw_zero_if: bad arguments");
-    hipLaunchKernelGGL(zero_if_kernel, dim3(grid_for(rows * cols)), dim3(kThreads), 0, as_stream(stream), A,
+    hipLaunchKernelGGL(zero_if_kernel, grid2d(rows, cols), dim3(kThreads), 0, as_stream(stream), A,
                        rows, cols, lda, flag_dev);
     NPW_LAUNCH_CHECK();
     return NPW_OK;
@@ -295,7 +285,7 @@ int npw_daxpby(int64_t rows, int64_t cols, double alpha, const double* X, int64_
                const double* Y, int64_t ldy, double* D, int64_t ldd, npw_stream_t stream) {
     if (rows <= 0 || cols <= 0) return NPW_OK;
     NPW_REQUIRE(X && Y && D && ldx >= cols && ldy >= cols && ldd >= cols, "npw_daxpby: bad arguments");
-    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(rows * cols)), dim3(kThreads), 0, as_stream(stream), rows,
+    hipLaunchKernelGGL(axpby_kernel, grid2d(rows, cols), dim3(kThreads), 0, as_stream(stream), rows,
                        cols, alpha, X, ldx, beta, Y, ldy, D, ldd);
     NPW_LAUNCH_CHECK();
     return NPW_OK;
@@ -318,7 +308,7 @@ int npw_dtri_keep(char uplo, int unit_diag, int64_t rows, int64_t cols, double* 
     NPW_REQUIRE(uplo == 'L' || uplo == 'U' || uplo == 'l' || uplo == 'u', "npw_dtri_keep: bad uplo");
     if (rows <= 0 || cols <= 0) return NPW_OK;
     NPW_REQUIRE(A != nullptr && lda >= cols, "npw_dtri_keep: bad arguments");
-    hipLaunchKernelGGL(tri_keep_kernel, dim3(grid_for(rows * cols)), dim3(kThreads), 0, as_stream(stream),
+    hipLaunchKernelGGL(tri_keep_kernel, grid2d(rows, cols), dim3(kThreads), 0, as_stream(stream),
                        uplo == 'L' || uplo == 'l', unit_diag != 0, rows, cols, A, lda);
     NPW_LAUNCH_CHECK();
     return NPW_OK;
@@ -330,7 +320,7 @@ int npw_convert(int64_t rows, int64_t cols, const void* src, int64_t lds, int sr
     NPW_REQUIRE(src != nullptr && dst != nullptr && lds >= cols && ldd >= cols, "npw_convert: bad arguments");
     NPW_REQUIRE((src_type == 0 || src_type == 1) && (dst_type == 0 || dst_type == 1), "npw_convert: bad type");
     hipStream_t s = as_stream(stream);
-    dim3 g(grid_for(rows * cols)), b(kThreads);
+    dim3 g = grid2d(rows, cols), b(kThreads);
     if (src_type == 0 && dst_type == 1)
         hipLaunchKernelGGL((convert_kernel<double, float>), g, b, 0, s, rows, cols, (const double*)src, lds, (float*)dst, ldd);
     else if (src_type == 1 && dst_type == 0)
@@ -347,7 +337,7 @@ int npw_fill_outer(double* A, int64_t rows, int64_t cols, int64_t lda, const dou
                    int64_t row0, int64_t col0, double lambda, npw_stream_t stream) {
     if (rows <= 0 || cols <= 0) return NPW_OK;
     NPW_REQUIRE(A != nullptr && x != nullptr && lda >= cols, "npw_fill_outer: bad arguments");
-    hipLaunchKernelGGL(fill_outer_kernel, dim3(grid_for(rows * cols)), dim3(kThreads), 0, as_stream(stream),
+    hipLaunchKernelGGL(fill_outer_kernel, grid2d(rows, cols), dim3(kThreads), 0, as_stream(stream),
                        A, rows, cols, lda, x, row0, col0, lambda);
     NPW_LAUNCH_CHECK();
     return NPW_OK;
@@ -357,7 +347,7 @@ int npw_fill_random(double* A, int64_t rows, int64_t cols, int64_t lda, uint64_t
                     int64_t row0, int64_t col0, npw_stream_t stream) {
     if (rows <= 0 || cols <= 0) return NPW_OK;
     NPW_REQUIRE(A != nullptr && lda >= cols, "npw_fill_random: bad arguments");
-    hipLaunchKernelGGL(fill_random_kernel, dim3(grid_for(rows * cols)), dim3(kThreads), 0, as_stream(stream),
+    hipLaunchKernelGGL(fill_random_kernel, grid2d(rows, cols), dim3(kThreads), 0, as_stream(stream),
                        A, rows, cols, lda, seed, row0, col0);
     NPW_LAUNCH_CHECK();
     return NPW_OK;
@@ -370,7 +360,7 @@ int npw_dsumsq(const double* A, int64_t rows, int64_t cols, int64_t lda, double*
     NPW_HIP_CHECK(hipMemsetAsync(out_dev, 0, sizeof(double), s));
     if (rows <= 0 || cols <= 0) return NPW_OK;
     NPW_REQUIRE(A != nullptr && lda >= cols, "npw_dsumsq: bad arguments");
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(rows * cols)), dim3(kThreads), 0, s, A, rows, cols, lda,
+    hipLaunchKernelGGL(sumsq_kernel, grid2d(rows, cols), dim3(kThreads), 0, s, A, rows, cols, lda,
                        out_dev);
     NPW_LAUNCH_CHECK();
     return NPW_OK;

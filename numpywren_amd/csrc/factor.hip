@@ -43,20 +43,36 @@ __device__ inline double readlane_d(double x, int src_lane) {  // src_lane must 
 // Cholesky of a 16x16 block held one row per lane (lane & 15 owns row li as a[0..15]); fully
 // unrolled, pivots and multipliers travel through v_readlane (no LDS, no barrier).
 // Returns false (wave-uniform) if a pivot is not positive; *bad_col gets its index.
-__device__ inline bool chol16(double (&a)[JB], int li, int* bad_col) {
+// 1/sqrt(d) and sqrt(d) to ~1 ulp from the hardware v_rsq_f64 estimate + two Newton steps: the
+// 128 pivots of a diagonal block form one serial dependency chain, so the sqrt + divide sequences
+// of the naive formulation (~300 cycles per pivot) are what the kernel waits for; this is ~5x shorter
+// and turns the column scaling into a multiplication.
+__device__ inline void rsqrt_sqrt(double d, double& rinv, double& root) {
+    double y = __builtin_amdgcn_rsq(d);
+    y = y * fma(-0.5 * d * y, y, 1.5);
+    y = y * fma(-0.5 * d * y, y, 1.5);
+    double l = d * y;
+    l = fma(0.5 * y, fma(-l, l, d), l);  // Heron correction: sqrt(d)
+    rinv = y * fma(-l, y, 2.0);          // 1 / l
+    root = l;
+}
+
+// Cholesky of a 16 x 16 block held one row per lane (lane & 15 owns row li as a[0..15]), fully unrolled;
+// pivots and multipliers travel through v_readlane (no LDS, no barrier).  rdiag[j] receives 1 / l_jj.
+// Returns false (wave-uniform) if a pivot is not positive; *bad_col gets its index.
+__device__ inline bool chol16(double (&a)[JB], double (&rdiag)[JB], int li, int* bad_col) {
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
-        double d = readlane_d(a[j], j);
+        const double d = readlane_d(a[j], j);
         if (!(d > 0.0) && ok) {
             ok = false;
             *bad_col = j;
         }
-        d = sqrt(d);
-        if (li == j)
-            a[j] = d;
-        else
-            a[j] = a[j] / d;  // rows below the pivot become l_ij (rows above hold don't-care values)
+        double rinv, root;
+        rsqrt_sqrt(d, rinv, root);
+        rdiag[j] = rinv;
+        a[j] = (li == j) ? root : a[j] * rinv;  // rows below the pivot become l_ij (rows above: don't care)
 #pragma unroll
         for (int k = j + 1; k < JB; ++k) {
             const double lkj = readlane_d(a[j], k);
@@ -66,17 +82,27 @@ __device__ inline bool chol16(double (&a)[JB], int li, int* bad_col) {
     return ok;
 }
 
-// inverse of the lower-triangular 16x16 block whose row r lives in lane r (a[0..15]):
-// lane c (= lane & 15) produces column c of the inverse in w[0..15].
-__device__ inline void trtri16(const double (&a)[JB], int c, double (&w)[JB]) {
+// inverse of the lower-triangular 16 x 16 block whose row r lives in lane r (a[0..15]); rdiag[r] = 1 / a_rr.
+// Lane c (= lane & 15) produces column c of the inverse in w[0..15].  Two partial sums halve the FMA chain.
+__device__ inline void trtri16(const double (&a)[JB], const double (&rdiag)[JB], int c, double (&w)[JB]) {
 #pragma unroll
     for (int r = 0; r < JB; ++r) {
-        const double lrr = readlane_d(a[r], r);
-        double s = 0.0;
+        double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-        for (int k = 0; k < r; ++k) s = fma(readlane_d(a[k], r), w[k], s);
-        w[r] = (r < c) ? 0.0 : ((r == c ? 1.0 : 0.0) - s) / lrr;
+        for (int k = 0; k < r; ++k) {
+            const double lrk = readlane_d(a[k], r);
+            if (k & 1)
+                s1 = fma(lrk, w[k], s1);
+            else
+                s0 = fma(lrk, w[k], s0);
+        }
+        w[r] = (r < c) ? 0.0 : ((r == c ? 1.0 : 0.0) - (s0 + s1)) * rdiag[r];
     }
+}
+
+__device__ inline void recip16(const double (&a)[JB], double (&rdiag)[JB]) {
+#pragma unroll
+    for (int r = 0; r < JB; ++r) rdiag[r] = 1.0 / readlane_d(a[r], r);
 }
 
 // Given L (lower, in S) and the inverses of its 16x16 diagonal sub-blocks (in Wd), overwrite
@@ -158,18 +184,18 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(int n, double*
     for (int jb = 0; jb < nbk && !failed; ++jb) {
         // (1) diagonal sub-block: factor + invert, one wave, registers only
         if (wave == 0) {
-            double a[JB], w[JB];
+            double a[JB], w[JB], rdiag[JB];
 #pragma unroll
             for (int k = 0; k < JB; ++k) a[k] = S[(jb * JB + li) * SLD + jb * JB + k];
             int bad_col = 0;
-            const bool ok = chol16(a, li, &bad_col);
+            const bool ok = chol16(a, rdiag, li, &bad_col);
             if (!ok) {
                 if (lane == 0) {
                     atomicCAS(info, 0, base + jb * JB + bad_col + 1);
                     *flag = 1;
                 }
             } else {
-                trtri16(a, li, w);
+                trtri16(a, rdiag, li, w);
                 if (lane < JB) {
 #pragma unroll
                     for (int k = 0; k < JB; ++k) {
@@ -267,10 +293,11 @@ __global__ __launch_bounds__(DIAG_THREADS) void trtri_diag_kernel(int n, const d
     }
     __syncthreads();
     for (int jb = wave; jb < nbk; jb += NWAVES) {
-        double a[JB], w[JB];
+        double a[JB], w[JB], rdiag[JB];
 #pragma unroll
         for (int k = 0; k < JB; ++k) a[k] = S[(jb * JB + li) * SLD + jb * JB + k];
-        trtri16(a, li, w);
+        recip16(a, rdiag);
+        trtri16(a, rdiag, li, w);
         if (lane < JB) {
 #pragma unroll
             for (int k = 0; k < JB; ++k) Wd[(jb * JB + k) * WLD + li] = w[k];
@@ -283,12 +310,9 @@ __global__ __launch_bounds__(DIAG_THREADS) void trtri_diag_kernel(int n, const d
 
 // dst = lower triangle of src (incl. diagonal), strict upper part = 0
 __global__ void tril_copy_kernel(int64_t n, const double* src, int64_t lds, double* dst, int64_t ldd) {
-    const int64_t total = n * n;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = idx / n, c = idx - r * n;
-        dst[r * ldd + c] = (c <= r) ? src[r * lds + c] : 0.0;
-    }
+    for (int64_t r = blockIdx.y; r < n; r += gridDim.y)
+        for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (int64_t)gridDim.x * blockDim.x)
+            dst[r * ldd + c] = (c <= r) ? src[r * lds + c] : 0.0;
 }
 
 int set_big_lds(const void* fn) {
@@ -301,30 +325,58 @@ inline int64_t split(int64_t n) {  // first-half size: multiple of NB, roughly n
     return (blocks / 2) * NB;
 }
 
-// X (m x n, columns [coff, coff+n) of the solve) <- X * L[coff:coff+n, coff:coff+n]^-T in place.
-// Winv holds the inverses of L's diagonal blocks (block index = column offset / NB).
-int trsm_rec(int64_t m, int64_t n, const double* L, int64_t ldl, int64_t coff, double* X, int64_t ldx,
-             const double* Winv, hipStream_t s) {
+inline size_t winv_bytes(int64_t n) { return (size_t)ceil_div(n, NB) * NB * NB * sizeof(double); }
+
+// State of one triangular solve  X * L^T = B  (X, B: m x n).
+//   Winv : inverses of L's NB x NB diagonal blocks (block index = absolute column offset / NB)
+//   T    : m x n scratch (ld = ldt).  Column blocks are *updated* in T and *solved* from T into X, so
+//          every GEMM is out of place and free to use the chip-filling tilings.  A column block that has
+//          not been updated yet still lives in B (only the very first leaf reads B).
+struct TrsmCtx {
+    int64_t m;
+    const double* L;
+    int64_t ldl;
+    const double* B;
+    int64_t ldb;
+    double* X;
+    int64_t ldx;
+    double* T;
+    int64_t ldt;
+    const double* Winv;
+    int64_t c0;  // absolute column offset of X's / B's / T's column 0 inside L (potrf panels)
+    hipStream_t s;
+};
+
+// solve the column range [coff, coff + n) (relative to the panel); `touched`: its current values are in T
+int trsm_rec(const TrsmCtx& c, int64_t coff, int64_t n, bool touched) {
     if (n <= NB) {
-        GemmOpts o;
+        const double* Wb = c.Winv + (size_t)((c.c0 + coff) / NB) * NB * NB;
+        double* Xj = c.X + coff;
+        if (touched)
+            return gemm<double>('N', 'T', c.m, n, n, 1.0, c.T + coff, c.ldt, Wb, NB, 0.0, nullptr, 0, Xj, c.ldx,
+                                GemmOpts(), c.s);
+        if ((const void*)c.B != (const void*)c.X)
+            return gemm<double>('N', 'T', c.m, n, n, 1.0, c.B + coff, c.ldb, Wb, NB, 0.0, nullptr, 0, Xj, c.ldx,
+                                GemmOpts(), c.s);
+        GemmOpts o;  // in-place solve of the first block of an in-place panel (row-panel tiling)
         o.inplace_a = true;
-        double* Xj = X + coff;
-        const double* Wb = Winv + (size_t)(coff / NB) * NB * NB;
-        return gemm<double>('N', 'T', m, n, n, 1.0, Xj, ldx, Wb, NB, 0.0, nullptr, 0, Xj, ldx, o, s);
+        return gemm<double>('N', 'T', c.m, n, n, 1.0, Xj, c.ldx, Wb, NB, 0.0, nullptr, 0, Xj, c.ldx, o, c.s);
     }
     const int64_t n1 = split(n), n2 = n - n1;
-    int rc = trsm_rec(m, n1, L, ldl, coff, X, ldx, Winv, s);
+    int rc = trsm_rec(c, coff, n1, touched);
     if (rc) return rc;
-    // X2 -= X1 * L21^T,  L21 = L[coff+n1 : coff+n, coff : coff+n1]
-    const double* L21 = L + (coff + n1) * ldl + coff;
-    double* X2 = X + coff + n1;
-    rc = gemm<double>('N', 'T', m, n2, n1, -1.0, X + coff, ldx, L21, ldl, 1.0, X2, ldx, X2, ldx, GemmOpts(), s);
+    // T2 = (T2 | B2) - X1 * L21^T,  L21 = L[c0+coff+n1 : c0+coff+n, c0+coff : c0+coff+n1]
+    const double* L21 = c.L + (c.c0 + coff + n1) * c.ldl + (c.c0 + coff);
+    const double* C2 = touched ? c.T + coff + n1 : c.B + coff + n1;
+    const int64_t ldc = touched ? c.ldt : c.ldb;
+    rc = gemm<double>('N', 'T', c.m, n2, n1, -1.0, c.X + coff, c.ldx, L21, c.ldl, 1.0, C2, ldc, c.T + coff + n1, c.ldt,
+                      GemmOpts(), c.s);
     if (rc) return rc;
-    return trsm_rec(m, n2, L, ldl, coff + n1, X, ldx, Winv, s);
+    return trsm_rec(c, coff + n1, n2, true);
 }
 
 // in-place Cholesky of the trailing n x n block of A starting at (off, off)
-int potrf_rec(int64_t n, int64_t off, double* A, int64_t lda, int32_t* info, double* Winv, hipStream_t s) {
+int potrf_rec(int64_t n, int64_t off, double* A, int64_t lda, int32_t* info, double* Winv, double* T, hipStream_t s) {
     double* Ab = A + off * lda + off;
     if (n <= NB) {
         hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, s, (int)n, Ab, lda, info,
@@ -333,20 +385,32 @@ int potrf_rec(int64_t n, int64_t off, double* A, int64_t lda, int32_t* info, dou
         return NPW_OK;
     }
     const int64_t n1 = split(n), n2 = n - n1;
-    int rc = potrf_rec(n1, off, A, lda, info, Winv, s);
+    int rc = potrf_rec(n1, off, A, lda, info, Winv, T, s);
     if (rc) return rc;
-    // A21 <- A21 * L11^-T : rows [off+n1, off+n), columns [off, off+n1).  trsm_rec indexes L and
-    // Winv by absolute column offset, so pass the panel shifted back by `off` columns.
-    double* A21 = A + (off + n1) * lda;  // row pointer, column 0
-    rc = trsm_rec(n2, n1, A, lda, off, A21, lda, Winv, s);
+    // A21 <- A21 * L11^-T : rows [off+n1, off+n), columns [off, off+n1), in place
+    double* A21 = A + (off + n1) * lda + off;
+    TrsmCtx c{n2, A, lda, A21, lda, A21, lda, T, n1, Winv, off, s};
+    rc = trsm_rec(c, 0, n1, false);
     if (rc) return rc;
     // A22 -= A21 A21^T (only tiles touching the lower triangle)
     double* A22 = A + (off + n1) * lda + (off + n1);
     GemmOpts o;
     o.lower_only = true;
-    rc = gemm<double>('N', 'T', n2, n2, n1, -1.0, A21 + off, lda, A21 + off, lda, 1.0, A22, lda, A22, lda, o, s);
+    rc = gemm<double>('N', 'T', n2, n2, n1, -1.0, A21, lda, A21, lda, 1.0, A22, lda, A22, lda, o, s);
     if (rc) return rc;
-    return potrf_rec(n2, off + n1, A, lda, info, Winv, s);
+    return potrf_rec(n2, off + n1, A, lda, info, Winv, T, s);
+}
+
+int ensure_big_lds() {
+    static thread_local bool attr = false;
+    if (!attr) {
+        int rc = set_big_lds(reinterpret_cast<const void*>(trtri_diag_kernel));
+        if (rc) return rc;
+        rc = set_big_lds(reinterpret_cast<const void*>(potrf_diag_kernel));
+        if (rc) return rc;
+        attr = true;
+    }
+    return NPW_OK;
 }
 
 }  // namespace
@@ -356,10 +420,46 @@ using namespace npw;
 
 extern "C" {
 
+size_t npw_dtrtri_diag_bytes(int64_t n) { return n <= 0 ? 0 : winv_bytes(n); }
+
+int npw_dtrtri_diag(int64_t n, const double* L, int64_t ldl, double* Winv, npw_stream_t stream) {
+    NPW_REQUIRE(n >= 0, "npw_dtrtri_diag: negative dimension");
+    if (n == 0) return NPW_OK;
+    NPW_REQUIRE(L && Winv && ldl >= n, "npw_dtrtri_diag: bad arguments");
+    int rc = ensure_big_lds();
+    if (rc) return rc;
+    const int nblk = (int)ceil_div(n, NB);
+    hipLaunchKernelGGL(trtri_diag_kernel, dim3(nblk), dim3(DIAG_THREADS), DIAG_LDS_BYTES, as_stream(stream), (int)n, L,
+                       ldl, Winv);
+    NPW_LAUNCH_CHECK();
+    return NPW_OK;
+}
+
+size_t npw_dtrsm_rltn_inv_workspace_bytes(int64_t m, int64_t n) {
+    if (m <= 0 || n <= 0) return 0;
+    return (size_t)m * n * sizeof(double);
+}
+
+int npw_dtrsm_rltn_inv(int64_t m, int64_t n, const double* L, int64_t ldl, const double* Winv, const double* B,
+                       int64_t ldb, double* X, int64_t ldx, void* workspace, npw_stream_t stream) {
+    NPW_REQUIRE(m >= 0 && n >= 0, "npw_dtrsm_rltn_inv: negative dimension");
+    if (m == 0 || n == 0) return NPW_OK;
+    NPW_REQUIRE(L && Winv && B && X && workspace, "npw_dtrsm_rltn_inv: NULL argument");
+    NPW_REQUIRE(ldl >= n && ldb >= n && ldx >= n, "npw_dtrsm_rltn_inv: leading dimension too small");
+    NPW_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "npw_dtrsm_rltn_inv: workspace not 16B aligned");
+    if (X == B) {
+        NPW_REQUIRE(ldx == ldb, "npw_dtrsm_rltn_inv: X == B needs ldx == ldb");
+    } else {
+        NPW_REQUIRE(X + (m - 1) * ldx + n <= B || B + (m - 1) * ldb + n <= X,
+                    "npw_dtrsm_rltn_inv: X and B overlap without being identical");
+    }
+    TrsmCtx c{m, L, ldl, B, ldb, X, ldx, static_cast<double*>(workspace), n, Winv, 0, as_stream(stream)};
+    return trsm_rec(c, 0, n, false);
+}
+
 size_t npw_dtrsm_rltn_workspace_bytes(int64_t m, int64_t n) {
-    (void)m;
-    if (n <= 0) return 0;
-    return (size_t)ceil_div(n, NB) * NB * NB * sizeof(double);
+    if (m <= 0 || n <= 0) return 0;
+    return winv_bytes(n) + npw_dtrsm_rltn_inv_workspace_bytes(m, n);
 }
 
 int npw_dtrsm_rltn(int64_t m, int64_t n, const double* L, int64_t ldl, const double* B,
@@ -367,33 +467,17 @@ int npw_dtrsm_rltn(int64_t m, int64_t n, const double* L, int64_t ldl, const dou
     NPW_REQUIRE(m >= 0 && n >= 0, "npw_dtrsm_rltn: negative dimension");
     if (m == 0 || n == 0) return NPW_OK;
     NPW_REQUIRE(L && B && X && workspace, "npw_dtrsm_rltn: NULL argument");
-    NPW_REQUIRE(ldl >= n && ldb >= n && ldx >= n, "npw_dtrsm_rltn: leading dimension too small");
     NPW_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "npw_dtrsm_rltn: workspace not 16B aligned");
-    hipStream_t s = as_stream(stream);
-    static thread_local bool attr = false;
-    if (!attr) {
-        int rc = set_big_lds(reinterpret_cast<const void*>(trtri_diag_kernel));
-        if (rc) return rc;
-        attr = true;
-    }
     double* Winv = static_cast<double*>(workspace);
-    const int nblk = (int)ceil_div(n, NB);
-    hipLaunchKernelGGL(trtri_diag_kernel, dim3(nblk), dim3(DIAG_THREADS), DIAG_LDS_BYTES, s, (int)n, L, ldl, Winv);
-    NPW_LAUNCH_CHECK();
-    if (X != B) {
-        NPW_REQUIRE(X + (m - 1) * ldx + n <= B || B + (m - 1) * ldb + n <= X,
-                    "npw_dtrsm_rltn: X and B overlap without being identical");
-        NPW_HIP_CHECK(hipMemcpy2DAsync(X, ldx * sizeof(double), B, ldb * sizeof(double), n * sizeof(double), m,
-                                       hipMemcpyDeviceToDevice, s));
-    } else {
-        NPW_REQUIRE(ldx == ldb, "npw_dtrsm_rltn: X == B needs ldx == ldb");
-    }
-    return trsm_rec(m, n, L, ldl, 0, X, ldx, Winv, s);
+    int rc = npw_dtrtri_diag(n, L, ldl, Winv, stream);
+    if (rc) return rc;
+    return npw_dtrsm_rltn_inv(m, n, L, ldl, Winv, B, ldb, X, ldx, static_cast<char*>(workspace) + winv_bytes(n), stream);
 }
 
 size_t npw_dpotrf_lower_workspace_bytes(int64_t n) {
     if (n <= 0) return 0;
-    return (size_t)ceil_div(n, NB) * NB * NB * sizeof(double);
+    const int64_t h = n - split(n);  // largest panel: (n - n1) x n1
+    return winv_bytes(n) + (size_t)h * (size_t)(n > NB ? split(n) : 0) * sizeof(double);
 }
 
 int npw_dpotrf_lower(int64_t n, const double* A, int64_t lda, double* Lout, int64_t ldl,
@@ -406,23 +490,21 @@ int npw_dpotrf_lower(int64_t n, const double* A, int64_t lda, double* Lout, int6
     NPW_REQUIRE(A && Lout && workspace, "npw_dpotrf_lower: NULL argument");
     NPW_REQUIRE(lda >= n && ldl >= n, "npw_dpotrf_lower: leading dimension too small");
     NPW_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "npw_dpotrf_lower: workspace not 16B aligned");
-    static thread_local bool attr = false;
-    if (!attr) {
-        int rc = set_big_lds(reinterpret_cast<const void*>(potrf_diag_kernel));
-        if (rc) return rc;
-        attr = true;
-    }
+    int rc = ensure_big_lds();
+    if (rc) return rc;
     if (Lout == A) {
         NPW_REQUIRE(lda == ldl, "npw_dpotrf_lower: Lout == A needs lda == ldl");
-        int rc = npw_dtri_keep('L', 0, n, n, Lout, ldl, stream);
+        rc = npw_dtri_keep('L', 0, n, n, Lout, ldl, stream);
         if (rc) return rc;
     } else {
-        int64_t blocks = ceil_div(n * n, 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(tril_copy_kernel, dim3((int)blocks), dim3(256), 0, s, n, A, lda, Lout, ldl);
+        const unsigned gx = (unsigned)(ceil_div(n, 256) > 16 ? 16 : ceil_div(n, 256));
+        const unsigned gy = (unsigned)(n > 256 ? 256 : n);
+        hipLaunchKernelGGL(tril_copy_kernel, dim3(gx, gy), dim3(256), 0, s, n, A, lda, Lout, ldl);
         NPW_LAUNCH_CHECK();
     }
-    return potrf_rec(n, 0, Lout, ldl, info_dev, static_cast<double*>(workspace), s);
+    double* Winv = static_cast<double*>(workspace);
+    double* T = reinterpret_cast<double*>(static_cast<char*>(workspace) + winv_bytes(n));
+    return potrf_rec(n, 0, Lout, ldl, info_dev, Winv, T, s);
 }
 
 }  // extern "C"

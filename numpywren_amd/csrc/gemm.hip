@@ -401,8 +401,11 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
     constexpr int VEC = 16 / (int)sizeof(T);
     auto aligned16 = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
     const bool vec_ok = aligned16(A) && aligned16(B) && (lda % VEC == 0) && (ldb % VEC == 0);
-    constexpr int BK = 16;
-    const bool k_ok = (k % BK == 0);
+    // k-tile depth: 16 for the 128 x 128 tiling (2 workgroups per CU hide each other's barrier and
+    // load latency), 32 for the small tilings, whose grids are often far below one workgroup per CU:
+    // there every k-tile is a dependent global-memory round trip, so fewer, deeper k-tiles win.
+    constexpr int BK = 16, BKS = 32;
+    const bool k_ok = (k % BK == 0), ks_ok = (k % BKS == 0);
 
     if (opts.inplace_a) {
         // D aliases A: legal because with a single tile column every workgroup reads only the rows
@@ -411,9 +414,9 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
                     "gemm: inplace_a needs op(A)=N, n,k <= 128 and D == A");
         p.tiles_m = (int)ceil_div(m, 64);
         p.tiles_n = 1;
-        const bool full = vec_ok && k_ok && (m % 64 == 0) && (n == 128);
-        if (full) return dispatch_layout<T, 64, 128, BK, false>(a_kc, b_kc, p, stream);
-        return dispatch_layout<T, 64, 128, BK, true>(a_kc, b_kc, p, stream);
+        const bool full = vec_ok && ks_ok && (m % 64 == 0) && (n == 128);
+        if (full) return dispatch_layout<T, 64, 128, BKS, false>(a_kc, b_kc, p, stream);
+        return dispatch_layout<T, 64, 128, BKS, true>(a_kc, b_kc, p, stream);
     }
     // tile selection: 128x128 when it fills the chip (or the problem is large), else 64x64
     const int64_t wg128 = ceil_div(m, 128) * ceil_div(n, 128);
@@ -427,9 +430,9 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
     }
     p.tiles_m = (int)ceil_div(m, 64);
     p.tiles_n = (int)ceil_div(n, 64);
-    const bool full = vec_ok && k_ok && (m % 64 == 0) && (n % 64 == 0);
-    if (full) return dispatch_layout<T, 64, 64, BK, false>(a_kc, b_kc, p, stream);
-    return dispatch_layout<T, 64, 64, BK, true>(a_kc, b_kc, p, stream);
+    const bool full = vec_ok && ks_ok && (m % 64 == 0) && (n % 64 == 0);
+    if (full) return dispatch_layout<T, 64, 64, BKS, false>(a_kc, b_kc, p, stream);
+    return dispatch_layout<T, 64, 64, BKS, true>(a_kc, b_kc, p, stream);
 }
 
 template int gemm<double>(char, char, int64_t, int64_t, int64_t, double, const double*, int64_t,

@@ -171,6 +171,14 @@ int npw_stream_create(npw_stream_t* stream, int high_priority) {
     return NPW_OK;
 }
 
+int npw_stream_create_masked(npw_stream_t* stream, const uint32_t* cu_mask, int words) {
+    NPW_REQUIRE(stream != nullptr && cu_mask != nullptr && words > 0, "npw_stream_create_masked: bad arguments");
+    hipStream_t s;
+    NPW_HIP_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, cu_mask));
+    *stream = reinterpret_cast<npw_stream_t>(s);
+    return NPW_OK;
+}
+
 int npw_stream_destroy(npw_stream_t stream) {
     if (stream) NPW_HIP_CHECK(hipStreamDestroy(as_stream(stream)));
     return NPW_OK;

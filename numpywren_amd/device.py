@@ -44,13 +44,14 @@ class Stream(object):
 
 class DeviceBuffer(object):
     """A raw HBM allocation owned by the backend's pool; returned to the pool when garbage collected."""
-    __slots__ = ("ptr", "nbytes", "_backend", "streams", "__weakref__")
+    __slots__ = ("ptr", "nbytes", "_backend", "streams", "aux", "__weakref__")
 
     def __init__(self, backend, ptr, nbytes):
         self.ptr = ptr
         self.nbytes = nbytes
         self._backend = backend
         self.streams = set()  # handles of the streams that accessed this buffer
+        self.aux = None       # derived data kept alive with the buffer (e.g. a factor's block inverses)
 
     def __del__(self):
         be = self._backend
@@ -148,8 +149,16 @@ class HipBackend(object):
         for i in range(1, max(1, num_streams)):
             self.streams.append(self.create_stream(name=f"s{i}"))
         self.priority_stream = self.create_stream(high_priority=True, name="prio")
+        # bulk streams: throughput kernels (trailing updates) are kept off `reserve_cus` compute units so
+        # that the latency-bound panel kernels of the priority stream always find a free slot
+        self.reserve_cus = int(os.environ.get("NUMPYWREN_AMD_RESERVE_CUS", "0"))
+        self.bulk_streams = []
+        if 0 < self.reserve_cus < self.compute_units:
+            for i in range(max(1, num_streams)):
+                self.bulk_streams.append(self.create_masked_stream(self.reserve_cus, name=f"bulk{i}"))
         self._zero_tiles = {}
         self._tls = threading.local()
+        self.kernel_timers = None  # name -> [(start_event, stop_event)] when enabled (bench.py roofline)
 
     # ------------------------------------------------------------------ device / threads
     def bind_thread(self):
@@ -169,6 +178,27 @@ class HipBackend(object):
         h = ctypes.c_void_p(0)
         _ffi.check(self.lib.npw_stream_create(ctypes.byref(h), 1 if high_priority else 0), "npw_stream_create")
         return Stream(h.value, high_priority, name)
+
+    def create_masked_stream(self, reserve_cus, name=""):
+        """A stream restricted to all CUs except `reserve_cus` of them (spread over the XCDs)."""
+        ncu = self.compute_units
+        words = (ncu + 31) // 32
+        mask = [0xFFFFFFFF] * words
+        if ncu % 32:
+            mask[-1] = (1 << (ncu % 32)) - 1
+        # drop every (ncu // reserve)-th CU so the reserved ones are spread over all XCDs under either
+        # CU-numbering convention (XCD-major or interleaved)
+        step = max(1, ncu // reserve_cus)
+        dropped = 0
+        cu = step // 2
+        while dropped < reserve_cus and cu < ncu:
+            mask[cu // 32] &= ~(1 << (cu % 32))
+            cu += step
+            dropped += 1
+        arr = (ctypes.c_uint32 * words)(*mask)
+        h = ctypes.c_void_p(0)
+        _ffi.check(self.lib.npw_stream_create_masked(ctypes.byref(h), arr, words), "npw_stream_create_masked")
+        return Stream(h.value, False, name)
 
     def _sh(self, stream):
         if stream is None:
@@ -219,6 +249,34 @@ class HipBackend(object):
 
     def synchronize(self):
         _ffi.check(self.lib.npw_device_synchronize(), "npw_device_synchronize")
+
+    # ------------------------------------------------------------------ per-kernel timing
+    def enable_kernel_timers(self, names=("syrk",)):
+        """Bracket the named kernels with timing events recorded on the stream they are launched on."""
+        self.kernel_timers = {n: [] for n in names}
+
+    def _tic(self, name, sh):
+        if self.kernel_timers is None or name not in self.kernel_timers:
+            return None
+        ev = self.new_event(timing=True)
+        self.record(ev, sh)
+        return ev
+
+    def _toc(self, name, sh, ev0):
+        if ev0 is None:
+            return
+        ev1 = self.new_event(timing=True)
+        self.record(ev1, sh)
+        self.kernel_timers[name].append((ev0, ev1))
+
+    def collect_kernel_times(self):
+        """{name: [milliseconds per launch]}; synchronises the device."""
+        self.synchronize()
+        out = {}
+        for name, pairs in (self.kernel_timers or {}).items():
+            out[name] = [self.elapsed_ms(a, b) for a, b in pairs]
+        self.kernel_timers = None
+        return out
 
     # ------------------------------------------------------------------ allocator
     def _alloc_raw(self, nbytes):
@@ -475,9 +533,11 @@ class HipBackend(object):
             fy = fx if Y is X else self.zero_flag(Y, sh)
         out = S if (inplace and not S.shared) else self.empty((m, n), _F64)
         self._use(sh, S, X, Y, out)
+        t0 = self._tic("syrk", sh)
         _ffi.check(self.lib.npw_dgemm_nt_sub(m, n, k, S.ptr, n, X.ptr, k, Y.ptr, k, out.ptr, n,
                                              fx.ptr if fx is not None else None, fy.ptr if fy is not None else None,
                                              sh), "syrk")
+        self._toc("syrk", sh, t0)
         self._produced(sh, out)
         return out
 
@@ -492,10 +552,27 @@ class HipBackend(object):
             raise ValueError(f"trsm: incompatible shapes x{L.shape} y{Y.shape}")
         m = Y.shape[0]
         out = self.empty((m, n), _F64)
-        ws = self.alloc(max(16, self.lib.npw_dtrsm_rltn_workspace_bytes(m, n)))
-        ws.streams.add(sh)
         self._use(sh, L, Y, out)
-        _ffi.check(self.lib.npw_dtrsm_rltn(m, n, L.ptr, n, Y.ptr, n, out.ptr, n, ws.ptr, sh), "trsm")
+        # the inverses of L's diagonal blocks are computed once per factor and shared by every trsm
+        # task that uses it (a whole block column of the Cholesky DAG)
+        aux = L.buf.aux if L.buf.aux is not None else {}
+        cached = aux.get("diag_inv")
+        if cached is None:
+            winv = self.alloc(max(16, self.lib.npw_dtrtri_diag_bytes(n)))
+            winv.streams.add(sh)
+            _ffi.check(self.lib.npw_dtrtri_diag(n, L.ptr, n, winv.ptr, sh), "trtri_diag")
+            cached = (winv, (self.record_new(sh), sh))
+            aux["diag_inv"] = cached
+            L.buf.aux = aux
+        winv, ready = cached
+        if ready is not None and ready[1] != sh:
+            self.wait_event(sh, ready[0])
+        winv.streams.add(sh)
+        ws = self.alloc(max(16, self.lib.npw_dtrsm_rltn_inv_workspace_bytes(m, n)))
+        ws.streams.add(sh)
+        t0 = self._tic("trsm", sh)
+        _ffi.check(self.lib.npw_dtrsm_rltn_inv(m, n, L.ptr, n, winv.ptr, Y.ptr, n, out.ptr, n, ws.ptr, sh), "trsm")
+        self._toc("trsm", sh, t0)
         if exact_zero:
             # reference: `if np.allclose(y, 0): return np.zeros(...)` -- a device-side select
             fy = self.zero_flag(Y, sh)
@@ -518,8 +595,12 @@ class HipBackend(object):
         ws = self.alloc(max(16, self.lib.npw_dpotrf_lower_workspace_bytes(n)))
         ws.streams.add(sh)
         self._use(sh, A, out)
+        t0 = self._tic("chol", sh)
         _ffi.check(self.lib.npw_dpotrf_lower(n, A.ptr, n, out.ptr, n, info.ptr, ws.ptr, sh), "chol")
+        self._toc("chol", sh, t0)
         self._produced(sh, out)
+        # the workspace starts with the inverses of the factor's diagonal blocks: keep them with L
+        out.buf.aux = {"diag_inv": (ws, None)}
         return out, info
 
     def add_n(self, tiles, stream=None):

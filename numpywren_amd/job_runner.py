@@ -78,9 +78,10 @@ class LambdaPackExecutor(object):
         cfg = (program.config or {}).get("executor", {}) if isinstance(program.config, dict) else {}
         self.exact_zero = cfg.get("exact_zero_shortcircuit", True) if exact_zero is None else exact_zero
         self.reclaim = cfg.get("reclaim_intermediates", False)
-        n = max(1, min(int(pipeline_width), len(self.be.streams)))
-        self.streams = self.be.streams[:n]
-        self.prio_stream = self.be.priority_stream if cfg.get("priority_stream", True) else None
+        pool = getattr(self.be, "bulk_streams", None) or self.be.streams
+        n = max(1, min(int(pipeline_width), len(pool)))
+        self.streams = pool[:n]
+        self.prio_stream = self.be.priority_stream if cfg.get("priority_stream", False) else None
         self._rr = 0
         self.compiled = program.program
         self._readers_left = None
@@ -211,7 +212,7 @@ def check_info_flags(program, be):
     return True
 
 
-def lambdapack_run(program, pipeline_width=5, msg_vis_timeout=60, cache_size=5, timeout=200, idle_timeout=5,
+def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, timeout=200, idle_timeout=5,
                    msg_vis_timeout_jitter=15, compute_threads=1, max_inflight=64):
     """Run `program` to completion (or until `timeout` seconds) on the local GPU.
 

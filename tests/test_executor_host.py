@@ -49,6 +49,7 @@ def test_cholesky_streams_and_priority(oracle_backend):
     X = BigMatrix("chol_streams", shape=A.shape, shard_sizes=(8, 8))
     shard_matrix(X, A)
     program, meta = alg_wrappers.cholesky(X)
+    program.config["executor"]["priority_stream"] = True
     run(program, pipeline_width=3)
     prio = {s for k, s in oracle_backend.calls if k in ("chol", "trsm")}
     bulk = {s for k, s in oracle_backend.calls if k == "syrk"}
