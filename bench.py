@@ -122,7 +122,7 @@ def main():
     from numpywren_amd.device import get_backend
 
     comm = None
-    if world > 1:
+    if world > 1 or os.environ.get("NUMPYWREN_AMD_FORCE_DIST"):   # the env var exercises the N > 1 code path on 1 GPU
         from numpywren_amd import dist
         comm = dist.init_process_group()   # RCCL over xGMI, one process per GPU
     be = get_backend()

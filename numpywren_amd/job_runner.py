@@ -71,9 +71,12 @@ def calculate_busy_time(rtimes):
 class LambdaPackExecutor(object):
     """Executes single tasks of a program on the HIP backend."""
 
-    def __init__(self, program, loop=None, cache=None, read_queue=None, pipeline_width=4, exact_zero=None):
+    def __init__(self, program, loop=None, cache=None, read_queue=None, pipeline_width=4, exact_zero=None,
+                 is_local=None, send_plan=None):
         self.program = program
         self.cache = cache
+        self.is_local = is_local      # multi-GPU: predicate "this rank executes the task"
+        self.send_plan = send_plan    # multi-GPU: task -> {output position: remote consumer ranks}
         self.be = get_backend()
         cfg = (program.config or {}).get("executor", {}) if isinstance(program.config, dict) else {}
         self.exact_zero = cfg.get("exact_zero_shortcircuit", True) if exact_zero is None else exact_zero
@@ -99,10 +102,30 @@ class LambdaPackExecutor(object):
         left = collections.Counter()
         keep = set(self.compiled.inputs) | set(self.compiled.outputs)
         for t in self.compiled.tasks:
-            for r in set(t.reads):
-                if r[0] not in keep and self.compiled.writer_of(*r) is not None:
-                    left[r] += 1
+            local = self.is_local is None or self.is_local(t)
+            if local:
+                for r in set(t.reads):
+                    if r[0] not in keep and self.compiled.writer_of(*r) is not None:
+                        left[r] += 1
+                if self.send_plan is not None:
+                    # a tile that still has to be pushed to another GPU is kept until it has been sent
+                    for pos in self.send_plan(t):
+                        w = t.writes[pos]
+                        if w[0] not in keep:
+                            left[w] += 1
         self._readers_left = left
+
+    def sent(self, name, idx):
+        """Multi-GPU: the tile has been handed to the transport for all its remote consumers."""
+        if not self.reclaim:
+            return
+        if self._readers_left is None:
+            self._init_reclaim()
+        w = (name, tuple(idx))
+        if w in self._readers_left:
+            self._readers_left[w] -= 1
+            if self._readers_left[w] == 0:
+                self.compiled.matrices[name].delete_block(*idx)
 
     def _consumed(self, task):
         if not self.reclaim:
