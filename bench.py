@@ -195,7 +195,7 @@ def main():
         if syrk:
             avg_ms = float(np.mean(syrk))
             achieved = 2.0 * b ** 3 / (avg_ms * 1e-3) / 1e12
-            line["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<double,128,128,16,KC,KC> (syrk: S - X Y^T)",
+            line["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<double,128,128,16,true,true,false,1> (kernels.syrk: S - X Y^T, 1024 workgroups)",
                                 "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                                 "launches": len(syrk), "avg_ms": round(avg_ms, 4),

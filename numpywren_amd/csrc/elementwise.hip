@@ -86,14 +86,24 @@ __global__ void init_flag_kernel(int32_t* flag, int32_t v) { *flag = v; }
 
 __global__ void is_zero_kernel(const double* A, int64_t rows, int64_t cols, int64_t lda, double atol,
                                int32_t* flag) {
+    // The answer for a dense tile is known after the first non-zero element: every workgroup polls the
+    // flag (relaxed, L2) once per row and leaves as soon as any workgroup has cleared it, and only waves
+    // that still see it set issue the (contended) atomic -- a dense 128 MiB tile costs a few microseconds
+    // instead of a full sweep plus 32k serialized atomics.
     bool bad = false;
-    NPW_FOR_2D(r, c, rows, cols) {
-        const double v = A[r * lda + c];
-        // np.allclose(v, 0): |v - 0| <= atol + rtol*|0|, and non-finite values never match
-        if (!(fabs(v) <= atol)) bad = true;
+    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+        for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += (int64_t)gridDim.x * blockDim.x) {
+            const double v = A[r * lda + c];
+            // np.allclose(v, 0): |v - 0| <= atol + rtol*|0|, and non-finite values never match
+            if (!(fabs(v) <= atol)) bad = true;
+        }
+        if (__any(bad)) break;
     }
     if (__any(bad)) {
-        if ((threadIdx.x & 63) == 0) atomicAnd(flag, 0);
+        // every writer stores the same value, so a plain (relaxed, agent-scope) store is enough: unlike
+        // atomicAnd, same-address stores do not serialise one L2 round trip per wave
+        if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -87,6 +87,7 @@ struct GemmParams {
     const int32_t* skip1;
     int tiles_m, tiles_n;
     int lower_only;
+    int tag;
 };
 
 // XCD-aware + grouped mapping of the linear block id to an output tile.
@@ -112,7 +113,10 @@ __device__ inline void block_to_tile(int tiles_m, int tiles_n, int& tm, int& tn)
     tn = in_band / rows;
 }
 
-template <typename T, int BM, int BN, int BK, bool A_KC, bool B_KC, bool EDGE>
+// TAG only gives the kernel a distinct symbol: TAG 1 = the tile-level trailing update issued by
+// npw_dgemm_nt_sub (kernels.syrk), so profilers report it separately from the many smaller GEMMs that
+// trsm / potrf / geqrt run through the same tiling.
+template <typename T, int BM, int BN, int BK, bool A_KC, bool B_KC, bool EDGE, int TAG = 0>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p) {
     using TR = MfmaTraits<T>;
     using acc_t = typename TR::acc_t;
@@ -132,8 +136,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p) {
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* smem = reinterpret_cast<T*>(smem_raw);
-    T* As[2] = {smem, smem + A_ELEMS + B_ELEMS};
-    T* Bs[2] = {smem + A_ELEMS, smem + 2 * A_ELEMS + B_ELEMS};
+    // stage `buf` = [A tile | B tile] at element offset buf * STAGE.  Everything below indexes `smem`
+    // directly with integer offsets: going through an array of per-stage pointers makes hipcc lose the
+    // LDS address space and emit flat_load / flat_store (+ 64-bit address arithmetic) for every fragment.
+    constexpr int STAGE = A_ELEMS + B_ELEMS;
 
     int tile_m, tile_n;
     block_to_tile(p.tiles_m, p.tiles_n, tile_m, tile_n);
@@ -221,10 +227,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p) {
             const int id = tid + 256 * c;
             if constexpr (A_KC) {
                 const int row = id / (BK / VEC), kc = (id % (BK / VEC)) * VEC;
-                *reinterpret_cast<vec_t*>(&As[buf][row * LDKC + kc]) = ra[c];
+                *reinterpret_cast<vec_t*>(&smem[buf * STAGE + row * LDKC + kc]) = ra[c];
             } else {
                 const int kk = id / (BM / VEC), mc = (id % (BM / VEC)) * VEC;
-                *reinterpret_cast<vec_t*>(&As[buf][kk * LDA_MC + mc]) = ra[c];
+                *reinterpret_cast<vec_t*>(&smem[buf * STAGE + kk * LDA_MC + mc]) = ra[c];
             }
         }
 #pragma unroll
@@ -232,18 +238,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p) {
             const int id = tid + 256 * c;
             if constexpr (B_KC) {
                 const int row = id / (BK / VEC), kc = (id % (BK / VEC)) * VEC;
-                *reinterpret_cast<vec_t*>(&Bs[buf][row * LDKC + kc]) = rb[c];
+                *reinterpret_cast<vec_t*>(&smem[buf * STAGE + A_ELEMS + row * LDKC + kc]) = rb[c];
             } else {
                 const int kk = id / (BN / VEC), nc = (id % (BN / VEC)) * VEC;
-                *reinterpret_cast<vec_t*>(&Bs[buf][kk * LDB_MC + nc]) = rb[c];
+                *reinterpret_cast<vec_t*>(&smem[buf * STAGE + A_ELEMS + kk * LDB_MC + nc]) = rb[c];
             }
         }
     };
 
     // ---- LDS -> fragments -> MFMA ----------------------------------------------------------
     auto compute = [&](int buf) {
-        const T* a_s = As[buf];
-        const T* b_s = Bs[buf];
+        const T* a_s = smem + buf * STAGE;
+        const T* b_s = smem + buf * STAGE + A_ELEMS;
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             const int kk = k_of<T>(s, lg);
@@ -335,14 +341,28 @@ int launch(const GemmParams<T>& p, hipStream_t stream) {
     constexpr int A_ELEMS = A_KC ? BM * LDKC : BK * (BM + 16);
     constexpr int B_ELEMS = B_KC ? BN * LDKC : BK * (BN + 16);
     constexpr size_t smem = 2 * (A_ELEMS + B_ELEMS) * sizeof(T);
-    auto kern = gemm_kernel<T, BM, BN, BK, A_KC, B_KC, EDGE>;
+    const int nwg = p.tiles_m * p.tiles_n;
+    if constexpr (sizeof(T) == 8 && BM == 128 && BN == 128 && A_KC && B_KC && !EDGE) {
+        if (p.tag == 1) {
+            auto tagged = gemm_kernel<T, BM, BN, BK, A_KC, B_KC, EDGE, 1>;
+            static thread_local bool tagged_attr = false;
+            if (!tagged_attr) {
+                NPW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tagged),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                tagged_attr = true;
+            }
+            hipLaunchKernelGGL(tagged, dim3(nwg), dim3(256), smem, stream, p);
+            NPW_LAUNCH_CHECK();
+            return NPW_OK;
+        }
+    }
+    auto kern = gemm_kernel<T, BM, BN, BK, A_KC, B_KC, EDGE, 0>;
     static thread_local bool attr_set = false;
     if (!attr_set && smem > 48 * 1024) {
         NPW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    const int nwg = p.tiles_m * p.tiles_n;
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), smem, stream, p);
     NPW_LAUNCH_CHECK();
     return NPW_OK;
@@ -395,6 +415,7 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
     p.skip0 = opts.skip0;
     p.skip1 = opts.skip1;
     p.lower_only = opts.lower_only ? 1 : 0;
+    p.tag = opts.tag;
 
     const bool a_kc = !ta;  // A stored M x K  => k contiguous
     const bool b_kc = tb;   // B stored N x K  => k contiguous
@@ -472,6 +493,7 @@ int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t l
     npw::GemmOpts o;
     o.skip0 = skip_x;
     o.skip1 = skip_y;
+    o.tag = 1;
     return npw::gemm<double>('N', 'T', m, n, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, o,
                              npw::as_stream(stream));
 }

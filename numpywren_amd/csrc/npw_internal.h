@@ -47,6 +47,7 @@ struct GemmOpts {
     const int32_t* skip1 = nullptr;
     bool lower_only = false;  // only output tiles touching the lower triangle are computed/written
     bool inplace_a = false;   // D aliases A (row panel update, n <= 128): forces one tile column
+    int tag = 0;              // 1 = tile-level trailing update (separate kernel symbol for profiling)
 };
 
 // D = alpha * op(A) op(B) + beta * C
