@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense fp64 matrix peak (vendor spec; 74.6 measured by tools/devcheck)
 TILE = 4096
+SYRK_TRAFFIC_BYTES = 2.077e9    # measured, see profiles/r01_bench_rocprof_summary.md
 TILES_PER_SIDE = {1: 4, 2: 8, 4: 12, 8: 16}
 
 
@@ -197,7 +198,11 @@ def main():
             achieved = 2.0 * b ** 3 / (avg_ms * 1e-3) / 1e12
             line["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<double,128,128,16,true,true,false,1> (kernels.syrk: S - X Y^T, 1024 workgroups)",
                                 "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
+                                # HBM-side bytes per launch from the PMC passes of profiles/r01_bench_rocprof_summary.md
+                                # (2 x FETCH_SIZE + WRITE_SIZE); only meaningful for the 4096^2 tile it was measured on
+                                "traffic": SYRK_TRAFFIC_BYTES if b == TILE else None,
+                                "traffic_unit": "B/launch (PMC, separate passes; algorithmic 5.37e8)",
                                 "launches": len(syrk), "avg_ms": round(avg_ms, 4),
                                 "algorithmic_flop_per_launch": 2 * b ** 3}
             line["kernel_ms"] = {k: round(float(np.mean(v)), 4) for k, v in times.items() if v}
