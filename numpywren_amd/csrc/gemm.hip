@@ -88,6 +88,8 @@ struct GemmParams {
     int tiles_m, tiles_n;
     int lower_only;
     int tag;
+    int k_chunk;           // split-K: k range handled per blockIdx.y (0 = no split)
+    int64_t split_stride;  // split-K: element stride between the partial outputs
 };
 
 // XCD-aware + grouped mapping of the linear block id to an output tile.
@@ -152,7 +154,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p) {
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
     const int li = lane & 15, lg = lane >> 4;
 
-    int nk = (p.K + BK - 1) / BK;
+    // split-K: blockIdx.y selects the k range [kb, kend) and its own partial output
+    const int kb = p.k_chunk > 0 ? (int)blockIdx.y * p.k_chunk : 0;
+    const int kend = p.k_chunk > 0 ? min(p.K, kb + p.k_chunk) : p.K;
+    int nk = (kend - kb + BK - 1) / BK;
     if ((p.skip0 && *p.skip0) || (p.skip1 && *p.skip1)) nk = 0;
 
     acc_t acc[TM][TN];
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p) {
 
     // ---- global -> registers ------------------------------------------------------------
     auto load_tiles = [&](int kt) {
-        const int k0 = kt * BK;
+        const int k0 = kb + kt * BK;
 #pragma unroll
         for (int c = 0; c < A_CHUNKS; ++c) {
             const int id = tid + 256 * c;
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p) {
                 } else {
 #pragma unroll
                     for (int v = 0; v < VEC; ++v)
-                        ra[c][v] = (m0 + row < p.M && k0 + kc + v < p.K) ? src[v] : T(0);
+                        ra[c][v] = (m0 + row < p.M && k0 + kc + v < kend) ? src[v] : T(0);
                 }
             } else {  // A stored K x M
                 const int kk = id / (BM / VEC), mc = (id % (BM / VEC)) * VEC;
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p) {
                 } else {
 #pragma unroll
                     for (int v = 0; v < VEC; ++v)
-                        ra[c][v] = (k0 + kk < p.K && m0 + mc + v < p.M) ? src[v] : T(0);
+                        ra[c][v] = (k0 + kk < kend && m0 + mc + v < p.M) ? src[v] : T(0);
                 }
             }
         }
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p) {
                 } else {
 #pragma unroll
                     for (int v = 0; v < VEC; ++v)
-                        rb[c][v] = (n0 + row < p.N && k0 + kc + v < p.K) ? src[v] : T(0);
+                        rb[c][v] = (n0 + row < p.N && k0 + kc + v < kend) ? src[v] : T(0);
                 }
             } else {  // B stored K x N
                 const int kk = id / (BN / VEC), nc = (id % (BN / VEC)) * VEC;
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p) {
                 } else {
 #pragma unroll
                     for (int v = 0; v < VEC; ++v)
-                        rb[c][v] = (k0 + kk < p.K && n0 + nc + v < p.N) ? src[v] : T(0);
+                        rb[c][v] = (k0 + kk < kend && n0 + nc + v < p.N) ? src[v] : T(0);
                 }
             }
         }
@@ -290,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p) {
 
     // ---- epilogue: D = alpha * acc + beta * C ------------------------------------------------
     const T alpha = p.alpha, beta = p.beta;
+    T* const Dp = p.D + (int64_t)blockIdx.y * p.split_stride;
     // (the beta test is hoisted out of the unrolled loops: a per-element "load or not" select
     //  makes hipcc branch around and wait for every single load)
     if (beta != T(0)) {
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p) {
                 for (int r = 0; r < 4; ++r) {
                     const int row = m0 + wm0 + 16 * i + TR::acc_row(lg, r);
                     if (EDGE && (row >= p.M || col >= p.N)) continue;
-                    p.D[(int64_t)row * p.ldd + col] = fma(beta, cv[j][r], alpha * acc[i][j][r]);
+                    Dp[(int64_t)row * p.ldd + col] = fma(beta, cv[j][r], alpha * acc[i][j][r]);
                 }
             }
         }
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p) {
                 for (int r = 0; r < 4; ++r) {
                     const int row = m0 + wm0 + 16 * i + TR::acc_row(lg, r);
                     if (EDGE && (row >= p.M || col >= p.N)) continue;
-                    p.D[(int64_t)row * p.ldd + col] = alpha * acc[i][j][r];
+                    Dp[(int64_t)row * p.ldd + col] = alpha * acc[i][j][r];
                 }
             }
         }
@@ -342,6 +348,7 @@ int launch(const GemmParams<T>& p, hipStream_t stream) {
     constexpr int B_ELEMS = B_KC ? BN * LDKC : BK * (BN + 16);
     constexpr size_t smem = 2 * (A_ELEMS + B_ELEMS) * sizeof(T);
     const int nwg = p.tiles_m * p.tiles_n;
+    const int nsplit = p.k_chunk > 0 ? (p.K + p.k_chunk - 1) / p.k_chunk : 1;
     if constexpr (sizeof(T) == 8 && BM == 128 && BN == 128 && A_KC && B_KC && !EDGE) {
         if (p.tag == 1) {
             auto tagged = gemm_kernel<T, BM, BN, BK, A_KC, B_KC, EDGE, 1>;
@@ -351,7 +358,7 @@ int launch(const GemmParams<T>& p, hipStream_t stream) {
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
                 tagged_attr = true;
             }
-            hipLaunchKernelGGL(tagged, dim3(nwg), dim3(256), smem, stream, p);
+            hipLaunchKernelGGL(tagged, dim3(nwg, nsplit), dim3(256), smem, stream, p);
             NPW_LAUNCH_CHECK();
             return NPW_OK;
         }
@@ -363,7 +370,7 @@ int launch(const GemmParams<T>& p, hipStream_t stream) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), smem, stream, p);
+    hipLaunchKernelGGL(kern, dim3(nwg, nsplit), dim3(256), smem, stream, p);
     NPW_LAUNCH_CHECK();
     return NPW_OK;
 }
@@ -374,6 +381,20 @@ int dispatch_layout(bool a_kc, bool b_kc, const GemmParams<T>& p, hipStream_t s)
     if (a_kc && !b_kc) return launch<T, BM, BN, BK, true, false, EDGE>(p, s);
     if (!a_kc && b_kc) return launch<T, BM, BN, BK, false, true, EDGE>(p, s);
     return launch<T, BM, BN, BK, false, false, EDGE>(p, s);
+}
+
+// D = alpha * sum_s P[s] + beta * C over the split-K partial products P[s] (each m x n, contiguous)
+template <typename T>
+__global__ void splitk_reduce_kernel(int nsplit, const T* P, int64_t stride, int64_t m, int64_t n, T alpha, T beta,
+                                     const T* C, int64_t ldc, T* D, int64_t ldd) {
+    for (int64_t r = blockIdx.y; r < m; r += gridDim.y)
+        for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (int64_t)gridDim.x * blockDim.x) {
+            T acc = T(0);
+            for (int sidx = 0; sidx < nsplit; ++sidx) acc += P[sidx * stride + r * n + c];  // fixed order: deterministic
+            T v = alpha * acc;
+            if (beta != T(0)) v = fma(beta, C[r * ldc + c], v);
+            D[r * ldd + c] = v;
+        }
 }
 
 }  // namespace
@@ -398,6 +419,27 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
                 (long long)m, (long long)n, (long long)k, (long long)lda, (long long)ldb,
                 (long long)ldc, (long long)ldd);
 
+    // split-K for skinny outputs with a long contraction (e.g. V_p^T W in the QR update): the k range is
+    // cut into chunks that run as independent workgroups into partial products, summed in a fixed order.
+    if (opts.splitk > 1 && opts.splitk_ws != nullptr && opts.k_chunk_ == 0 && k >= 128) {
+        const int64_t chunk = ceil_div(ceil_div(k, (int64_t)opts.splitk), 32) * 32;
+        const int nsplit = (int)ceil_div(k, chunk);
+        if (nsplit > 1) {
+            GemmOpts inner = opts;
+            inner.splitk = 1;
+            inner.k_chunk_ = (int)chunk;
+            T* P = static_cast<T*>(opts.splitk_ws);
+            int rc = gemm<T>(transA, transB, m, n, k, T(1), A, lda, B, ldb, T(0), nullptr, 0, P, n, inner, stream);
+            if (rc) return rc;
+            const unsigned gx = (unsigned)(ceil_div(n, 256) > 16 ? 16 : ceil_div(n, 256));
+            const unsigned gy = (unsigned)(m > 1024 ? 1024 : m);
+            hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(gx, gy), dim3(256), 0, stream, nsplit, P, m * n, m, n, alpha,
+                               beta, C, ldc, D, ldd);
+            NPW_LAUNCH_CHECK();
+            return NPW_OK;
+        }
+    }
+
     GemmParams<T> p;
     p.A = A;
     p.B = B;
@@ -416,6 +458,8 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
     p.skip1 = opts.skip1;
     p.lower_only = opts.lower_only ? 1 : 0;
     p.tag = opts.tag;
+    p.k_chunk = opts.k_chunk_;
+    p.split_stride = opts.k_chunk_ > 0 ? m * n : 0;
 
     const bool a_kc = !ta;  // A stored M x K  => k contiguous
     const bool b_kc = tb;   // B stored N x K  => k contiguous

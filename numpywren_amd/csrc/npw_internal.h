@@ -48,6 +48,9 @@ struct GemmOpts {
     bool lower_only = false;  // only output tiles touching the lower triangle are computed/written
     bool inplace_a = false;   // D aliases A (row panel update, n <= 128): forces one tile column
     int tag = 0;              // 1 = tile-level trailing update (separate kernel symbol for profiling)
+    int splitk = 1;           // > 1 with splitk_ws: cut k into this many chunks (skinny outputs, long k)
+    void* splitk_ws = nullptr;  // splitk * m * n elements of scratch
+    int k_chunk_ = 0;         // internal: k range per blockIdx.y of the partial-product launch
 };
 
 // D = alpha * op(A) op(B) + beta * C

@@ -291,7 +291,7 @@ int main(int argc, char** argv) {
         for (int n : ns) bad += check_factor(n, n);
         bad += check_factor(200, 77);
         bad += check_factor(513, 1000);
-        int qs[][2] = {{1, 1}, {8, 8}, {16, 8}, {64, 32}, {100, 37}, {64, 64}, {256, 128}, {300, 300}, {512, 256}, {1024, 200}};
+        int qs[][2] = {{1, 1}, {8, 8}, {16, 8}, {64, 32}, {100, 37}, {64, 64}, {256, 128}, {300, 300}, {512, 256}, {1024, 200}, {2048, 96}, {1500, 70}, {3000, 33}, {1300, 300}};
         for (auto& q : qs) bad += check_qr(q[0], q[1]);
     }
     printf("correctness: %s (%d bad)\n", bad ? "FAILED" : "PASSED", bad);
