@@ -1,0 +1,117 @@
+#!/usr/bin/env python
+"""Secondary measurements for the BASELINE.json configs other than the headline (single GPU scale):
+
+    python tools/bench_aux.py gemm32  [--n 16384]       # configs[4] family: fp32 GEMM program, 4096^2 tiles
+    python tools/bench_aux.py tsqr    [--leaves 16]     # configs[3] family: (leaves*4096) x 4096 fp64 TSQR
+    python tools/bench_aux.py chol    [--tiles 8]       # the Cholesky DAG on a larger tile grid
+
+Each prints one JSON line.  Inputs are generated on the device and resident in HBM before timing;
+programs are compiled before the clock starts (like bench.py)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.pop("NUMPYWREN_AMD_STORE", None)
+
+from numpywren_amd import alg_wrappers, job_runner  # noqa: E402
+from numpywren_amd import lambdapack as lp  # noqa: E402
+from numpywren_amd.device import get_backend  # noqa: E402
+from numpywren_amd.matrix import BigMatrix  # noqa: E402
+
+
+def run(program, reclaim=True):
+    program.config["executor"]["reclaim_intermediates"] = reclaim
+    program.start()
+    job_runner.lambdapack_run(program, timeout=3600)
+    if program.program_status() != lp.PS.SUCCESS:
+        raise SystemExit(f"failed: {program.exceptions}")
+
+
+def timed(build, steps, warmup):
+    be = get_backend()
+    progs = [build() for _ in range(steps + warmup)]
+    for p, meta in progs:
+        p.program.tasks
+        p._priorities()
+    for i in range(warmup):
+        p, meta = progs.pop(0)
+        for m in meta["outputs"] + meta["intermediates"]:
+            m.free()
+        run(p)
+    be.synchronize()
+    t0 = time.time()
+    for p, meta in progs:
+        for m in meta["outputs"] + meta["intermediates"]:
+            m.free()
+        run(p)
+    be.synchronize()
+    return (time.time() - t0) / steps, meta
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["gemm32", "tsqr", "chol"])
+    ap.add_argument("--n", type=int, default=16384)
+    ap.add_argument("--leaves", type=int, default=16)
+    ap.add_argument("--tiles", type=int, default=8)
+    ap.add_argument("--tile", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    a = ap.parse_args()
+    be = get_backend()
+    b = a.tile
+    if a.what == "gemm32":
+        n = a.n
+        nb = n // b
+        A = BigMatrix("aux_A", shape=(n, n), shard_sizes=(b, b), dtype=np.float32)
+        B = BigMatrix("aux_B", shape=(n, n), shard_sizes=(b, b), dtype=np.float32)
+        for i in range(nb):
+            for j in range(nb):
+                A.put_tile(be.convert(be.fill_random((b, b), 11, i * b, j * b), np.float32), i, j)
+                B.put_tile(be.convert(be.fill_random((b, b), 12, i * b, j * b), np.float32), i, j)
+        dt, meta = timed(lambda: alg_wrappers.gemm(A, B), a.steps, a.warmup)
+        C = meta["outputs"][0]
+        # spot check one tile against a device-side fp64 product of the same operands
+        ref = None
+        for k in range(nb):
+            t = be.gemm(be.as_f64(A.get_tile(0, k)), be.as_f64(B.get_tile(k, 1)), alpha=1.0, beta=1.0 if ref else 0.0, C=ref)
+            ref = t
+        diff = be.axpby(1.0, be.as_f64(C.get_tile(0, 1)), -1.0, ref)
+        err = np.sqrt(be.sumsq(diff) / be.sumsq(ref))
+        print(json.dumps({"what": f"{n}^2 fp32 GEMM program (alg_wrappers.gemm), {b}^2 tiles, {len(meta and alg_wrappers.gemm(A, B)[0].program.tasks)} tasks",
+                          "ms": round(dt * 1e3, 2), "TFLOP/s": round(2 * n ** 3 / dt / 1e12, 2), "rel_err_tile_0_1": float(err),
+                          "note": "fp32 MFMA products, fp64 add_matrices tree (reference promotion quirk)"}))
+    elif a.what == "tsqr":
+        m = a.leaves * b
+        X = BigMatrix("aux_X", shape=(m, b), shard_sizes=(b, b))
+        for j in range(a.leaves):
+            X.put_tile(be.fill_random((b, b), 7, j * b, 0), j, 0)
+        dt, meta = timed(lambda: alg_wrappers.tsqr(X), a.steps, a.warmup)
+        levels = int(np.ceil(np.log2(a.leaves)))
+        R = meta["outputs"][0].get_tile(levels, 0)
+        # R^T R == A^T A
+        G = None
+        for j in range(a.leaves):
+            t = X.get_tile(j, 0)
+            G = be.gemm(t, t, True, False, alpha=1.0, beta=1.0 if G else 0.0, C=G)
+        D = be.gemm(R, R, True, False, alpha=1.0, beta=-1.0, C=G)
+        err = np.sqrt(be.sumsq(D) / be.sumsq(G))
+        flops = 2 * m * b * b - 2 * b ** 3 / 3
+        print(json.dumps({"what": f"{m} x {b} fp64 TSQR (alg_wrappers.tsqr), {a.leaves} leaves, {2 * a.leaves - 1} tasks",
+                          "ms": round(dt * 1e3, 2), "TFLOP/s(2mn^2-2n^3/3)": round(flops / dt / 1e12, 3),
+                          "rel_err_RtR": float(err)}))
+    else:
+        sys.argv = [sys.argv[0], "--tiles", str(a.tiles), "--tile", str(b), "--steps", str(a.steps), "--warmup", str(a.warmup),
+                    "--no-cpu-baseline"]
+        import bench
+        bench.main()
+
+
+if __name__ == "__main__":
+    main()
