@@ -61,6 +61,14 @@ class DeviceBuffer(object):
             except Exception:
                 pass
             self.ptr = 0
+        elif be is None and self.aux and "keepalive" in self.aux:
+            # memory owned by someone else (a torch tensor that received a tile over RCCL): its owner's
+            # allocator knows nothing about our streams, so the owner object is parked until every stream
+            # that touched the buffer has passed this point
+            try:
+                _defer_external_release(self.aux.pop("keepalive"), self.streams)
+            except Exception:
+                pass
 
 
 class DeviceTile(object):
@@ -249,6 +257,25 @@ class HipBackend(object):
 
     def synchronize(self):
         _ffi.check(self.lib.npw_device_synchronize(), "npw_device_synchronize")
+        self._external = []  # everything queued has completed: parked foreign owners can go
+
+    def defer_external(self, owner, streams):
+        """Keep `owner` (e.g. a torch tensor) alive until all `streams` have passed this point."""
+        events = []
+        for sh in streams:
+            ev = self.new_event()
+            _ffi.check(self.lib.npw_event_record(ev, sh))
+            events.append(ev)
+        with self._lock:
+            still = []
+            for o, evs in getattr(self, "_external", []):
+                if all(self.event_done(e) for e in evs):
+                    self._event_pool.extend(evs)
+                else:
+                    still.append((o, evs))
+            if events:
+                still.append((owner, events))
+            self._external = still
 
     # ------------------------------------------------------------------ per-kernel timing
     def enable_kernel_timers(self, names=("syrk",)):
@@ -746,6 +773,12 @@ class HipBackend(object):
 _backend = None
 _backend_lock = threading.Lock()
 _override = None
+
+
+def _defer_external_release(owner, streams):
+    be = _override if _override is not None else _backend
+    if be is not None and hasattr(be, "defer_external"):
+        be.defer_external(owner, streams)
 
 
 def get_backend():
