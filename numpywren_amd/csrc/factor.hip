@@ -3,20 +3,24 @@
 //   npw_dpotrf_lower  replaces kernels.chol (reference numpywren/kernels.py:225-226)
 //   npw_dtrsm_rltn    replaces kernels.trsm (reference numpywren/kernels.py:254-257)
 //
-// Both are recursive blocked algorithms whose flops live in the MFMA GEMM of gemm.hip:
+// The flops live in the MFMA GEMM of gemm.hip; this file supplies the latency-critical pieces and the order:
 //
-//   potrf(A):   A11 = potrf(A11);  A21 = A21 * L11^-T (trsm);  A22 -= A21 A21^T (lower tiles
-//               only);  A22 = potrf(A22)                         -- leaves are NB x NB blocks
-//   trsm(X,L):  X1 = trsm(X1, L11);  X2 -= X1 * L21^T;  X2 = trsm(X2, L22)
-//               leaf:  X_j = X_j * inv(L_jj)^T   (in-place row-panel GEMM)
+//   potrf(A):   right-looking over NB-wide block columns, three launches each:
+//               diagonal block (factor + invert, one workgroup, LDS-resident)  ->  panel P <- P inv(L_jj)^T
+//               (one in-place GEMM)  ->  trailing update A22 -= P P^T (one GEMM over the lower tiles only).
+//               (A recursive variant, potrf_rec, is kept behind NPW_POTRF_RECURSIVE=1 for comparison.)
+//   trsm(X,L):  recursive:  X1 = trsm(X1, L11);  X2 -= X1 * L21^T;  X2 = trsm(X2, L22)
+//               leaf:  X_j = X_j * inv(L_jj)^T   (GEMM with the cached inverse of the NB x NB diagonal block)
 //
-// The NB x NB (128) diagonal blocks are handled by one workgroup each, entirely in LDS, as a
-// blocked algorithm over 16 x 16 sub-blocks: the diagonal sub-block is factored and inverted
-// by one wave in registers (pivots broadcast with v_readlane), the panel / trailing /
-// inverse sub-block products run on v_mfma_f64_16x16x4_f64.  Multiplying by the explicit
-// inverse of a small diagonal block instead of substituting is the standard GPU trsm
-// formulation (the error grows with cond(L_jj) of the 128-wide block, not of the tile).
+// The NB x NB (128) diagonal blocks are handled by one workgroup each, entirely in LDS, as a blocked
+// algorithm over 16 x 16 sub-blocks with look-ahead between the waves (see potrf_diag_kernel).  The 16 x 16
+// factorisations keep one matrix row per lane and move multipliers with DPP row broadcasts; the sub-block
+// updates and the block inverse run on v_mfma_f64_16x16x4_f64.  Multiplying by the explicit inverse of a
+// small diagonal block instead of substituting is the standard GPU trsm formulation (the error grows with
+// cond(L_jj) of the 128-wide block, not of the tile).
 #include "npw_internal.h"
+
+#include <type_traits>
 
 namespace npw {
 namespace {
@@ -40,124 +44,363 @@ __device__ inline double readlane_d(double x, int src_lane) {  // src_lane must 
     return __hiloint2double(hi, lo);
 }
 
-// Cholesky of a 16x16 block held one row per lane (lane & 15 owns row li as a[0..15]); fully
-// unrolled, pivots and multipliers travel through v_readlane (no LDS, no barrier).
-// Returns false (wave-uniform) if a pivot is not positive; *bad_col gets its index.
-// 1/sqrt(d) and sqrt(d) to ~1 ulp from the hardware v_rsq_f64 estimate + two Newton steps: the
-// 128 pivots of a diagonal block form one serial dependency chain, so the sqrt + divide sequences
-// of the naive formulation (~300 cycles per pivot) are what the kernel waits for; this is ~5x shorter
-// and turns the column scaling into a multiplication.
-__device__ inline void rsqrt_sqrt(double d, double& rinv, double& root) {
-    double y = __builtin_amdgcn_rsq(d);
-    y = y * fma(-0.5 * d * y, y, 1.5);
-    y = y * fma(-0.5 * d * y, y, 1.5);
-    double l = d * y;
-    l = fma(0.5 * y, fma(-l, l, d), l);  // Heron correction: sqrt(d)
-    rinv = y * fma(-l, y, 2.0);          // 1 / l
-    root = l;
+// ---- cross-lane arithmetic inside a row of 16 lanes (DPP row_newbcast: every lane of the row reads lane K) ----
+// gfx950 offers DPP on the 64-bit ALU only for v_fmac / v_mov (v_rsq_f64_dpp assembles but returns garbage on
+// hardware) and only with row_newbcast, which is exactly what a 16 x 16 factorisation with one matrix row per
+// lane needs: the multiplier l_kj lives in lane k.  One instruction replaces the v_readlane x2 + wait state +
+// v_fma of the SGPR route.  Everything on the pivot chain is `asm volatile`: a wave issues in order, so the
+// only way to hide the ~10 dependent fp64 operations between two pivots is to place them *between* the
+// independent broadcast-FMAs by hand; left to the scheduler they end up back to back.
+// Hazards the assembler does not see inside inline asm: a DPP source written by the preceding VALU needs two
+// wait states (NOP = true where that can happen); the consumer of a transcendental result needs one.
+template <int K, bool NOP>
+__device__ inline void fnma_bcast(double& acc, double from_lane_k, double mine) {  // acc -= lane_K(from) * mine
+    if constexpr (NOP)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc)
+                     : "v"(from_lane_k), "v"(mine), "n"(K));
+    else
+        asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc)
+                     : "v"(from_lane_k), "v"(mine), "n"(K));
+}
+template <int K>
+__device__ inline double mov_bcast(double x) {
+    double y;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x), "n"(K));
+    return y;
+}
+__device__ inline double op_rsq(double x) {
+    double y;
+    asm volatile("v_rsq_f64 %0, %1\n\ts_nop 0" : "=v"(y) : "v"(x));
+    return y;
+}
+__device__ inline double op_mul(double a, double b) {
+    double y;
+    asm volatile("v_mul_f64 %0, %1, %2" : "=v"(y) : "v"(a), "v"(b));
+    return y;
+}
+__device__ inline double op_half(double a) {
+    double y;
+    asm volatile("v_mul_f64 %0, %1, 0.5" : "=v"(y) : "v"(a));
+    return y;
+}
+__device__ inline double op_fma(double a, double b, double c) {
+    double y;
+    asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(y) : "v"(a), "v"(b), "v"(c));
+    return y;
+}
+__device__ inline double op_one_minus(double a, double b) {  // 1 - a * b
+    double y;
+    asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(y) : "v"(a), "v"(b));
+    return y;
 }
 
-// Cholesky of a 16 x 16 block held one row per lane (lane & 15 owns row li as a[0..15]), fully unrolled;
-// pivots and multipliers travel through v_readlane (no LDS, no barrier).  rdiag[j] receives 1 / l_jj.
-// Returns false (wave-uniform) if a pivot is not positive; *bad_col gets its index.
-__device__ inline bool chol16(double (&a)[JB], double (&rdiag)[JB], int li, int* bad_col) {
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < JB; ++j) {
-        const double d = readlane_d(a[j], j);
-        if (!(d > 0.0) && ok) {
-            ok = false;
-            *bad_col = j;
+template <int I, int N, typename F>
+__device__ inline void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// 1/sqrt(d) from the hardware estimate y0 by two coupled (Goldschmidt) steps, cut into stages so that the
+// caller can spread them between independent instructions:
+//     g0 = d y0 (~sqrt d)   r0 = 1 - g0 y0   y1 = y0 + (y0/2) r0   g1 = g0 + (g0/2) r0
+//     r1 = 1 - g1 y1        rinv = y1 + (y1/2) r1
+// g and y carry the same relative error (g/y = d up to rounding), so r measures it and each step squares it:
+// ~1 ulp after two steps from any estimate better than 2^-14.  Dependent depth: rsq + 6.
+struct PivotChain {
+    double d, y0, g0, hh0, r0, gg, y1, g1, hh1, r1, rinv;
+    static constexpr int STAGES = 9;
+    template <int S>
+    __device__ inline void stage() {
+        if constexpr (S == 0) g0 = op_mul(d, y0);
+        if constexpr (S == 1) hh0 = op_half(y0);
+        if constexpr (S == 2) r0 = op_one_minus(g0, y0);
+        if constexpr (S == 3) gg = op_half(g0);
+        if constexpr (S == 4) y1 = op_fma(hh0, r0, y0);
+        if constexpr (S == 5) g1 = op_fma(gg, r0, g0);
+        if constexpr (S == 6) hh1 = op_half(y1);
+        if constexpr (S == 7) r1 = op_one_minus(g1, y1);
+        if constexpr (S == 8) rinv = op_fma(hh1, r1, y1);
+    }
+};
+
+// Cholesky of the 16 x 16 diagonal sub-block *and* the solve of 64 rows below it, in one instruction stream.
+// Lane (g, i) (g = lane >> 4, i = lane & 15) holds row i of the diagonal sub-block in a[0..15] -- the four
+// 16-lane rows carry identical copies, so every DPP row sees the whole sub-block -- and one row of the panel
+// in x[0..15].  Column step j:
+//     pivot d = a_jj (lane j), rinv = 1/sqrt(d);   a[j] *= rinv;  x[j] *= rinv       (l_jj = d * rinv)
+//     a[k] -= l_kj * a[j],  x[k] -= l_kj * x[j]   for k > j,   l_kj = a[j] of lane k  (DPP broadcast)
+// which is right-looking Cholesky on a[] and the forward substitution  X L^T = P  on x[].  Column j+1 is
+// updated first, its pivot chain is then issued in stages between the remaining updates of step j.
+// `bad` / `bad_col` are per-lane copies of wave-uniform values (first non-positive pivot).
+__device__ inline void chol16_panel(double (&a)[JB], double (&x)[JB], bool& bad, int& bad_col) {
+    bad = false;
+    bad_col = 0;
+    PivotChain c;
+    c.d = mov_bcast<0>(a[0]);
+    c.y0 = op_rsq(c.d);
+    static_for<0, PivotChain::STAGES>([&](auto S) { c.template stage<decltype(S)::value>(); });
+    static_for<0, JB>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        if (!bad && !(c.d > 0.0)) {
+            bad = true;
+            bad_col = j;
         }
-        double rinv, root;
-        rsqrt_sqrt(d, rinv, root);
-        rdiag[j] = rinv;
-        a[j] = (li == j) ? root : a[j] * rinv;  // rows below the pivot become l_ij (rows above: don't care)
+        a[j] = op_mul(a[j], c.rinv);
+        x[j] = op_mul(x[j], c.rinv);
+        if constexpr (j + 1 < JB) {
+            fnma_bcast<j + 1, true>(a[j + 1], a[j], a[j]);
+            fnma_bcast<j + 1, false>(x[j + 1], a[j], x[j]);
+            c.d = mov_bcast<j + 1>(a[j + 1]);
+            c.y0 = op_rsq(c.d);
+            static_for<j + 2, JB>([&](auto Kc) {
+                constexpr int k = decltype(Kc)::value;
+                fnma_bcast<k, false>(a[k], a[j], a[j]);
+                fnma_bcast<k, false>(x[k], a[j], x[j]);
+                constexpr int s = k - (j + 2);
+                if constexpr (s < PivotChain::STAGES) c.template stage<s>();
+            });
+            constexpr int done = (JB - (j + 2)) < 0 ? 0 : JB - (j + 2);
+            static_for<(done < PivotChain::STAGES ? done : PivotChain::STAGES), PivotChain::STAGES>(
+                [&](auto S) { c.template stage<decltype(S)::value>(); });
+        }
+    });
+}
+
+// Wd[jb] = inverse of the (final) diagonal sub-block jb of L in S; one wave (all four DPP rows compute the
+// same thing, row 0 stores).  Lane c builds column c of W = inv(L) right-looking:
+//     w = e_c;   for k: w[k] /= l_kk;  w[r] -= l_rk * w[k]  (r > k),   l_rk = a[k] of lane r  (DPP broadcast)
+__device__ inline void invert_diag16(const double* S, double* Wd, int jb, int lane) {
+    const int li = lane & 15;
+    double a[JB], w[JB];
+    const double2* p = reinterpret_cast<const double2*>(S + (jb * JB + li) * SLD + jb * JB);
 #pragma unroll
-        for (int k = j + 1; k < JB; ++k) {
-            const double lkj = readlane_d(a[j], k);
-            a[k] = fma(-a[j], lkj, a[k]);
+    for (int k = 0; k < JB / 2; ++k) {
+        const double2 v = p[k];
+        a[2 * k] = v.x;
+        a[2 * k + 1] = v.y;
+    }
+#pragma unroll
+    for (int k = 0; k < JB; ++k) w[k] = (k == li) ? 1.0 : 0.0;
+    static_for<0, JB>([&](auto Kc) {
+        constexpr int k = decltype(Kc)::value;
+        const double d = mov_bcast<k>(a[k]);
+        double y = __builtin_amdgcn_rcp(d);
+        y = y * fma(-d, y, 2.0);
+        y = y * fma(-d, y, 2.0);
+        w[k] *= y;
+        static_for<k + 1, JB>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            fnma_bcast<r, (r == k + 1)>(w[r], a[k], w[k]);
+        });
+    });
+    if (lane < JB) {
+#pragma unroll
+        for (int k = 0; k < JB; ++k) Wd[(jb * JB + k) * WLD + li] = w[k];  // W[r=k][c=li]
+    }
+}
+
+// The NB x NB block at `src` (lower triangle) -> S, identity-padded to the full NB x NB when n < NB.
+// All of a thread's loads are issued before the first LDS store (one memory round trip, not 32).
+__device__ inline void load_lower_block(double* S, const double* src, int64_t ld, int n, int tid) {
+    constexpr int PER = NB * NB / DIAG_THREADS;  // 32
+    constexpr int RSTEP = DIAG_THREADS / NB;     // 4
+    const int c = tid & (NB - 1), r0 = tid >> 7;
+    double v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int r = r0 + RSTEP * i;
+        v[i] = (r == c) ? 1.0 : 0.0;
+        if (c <= r && r < n) v[i] = src[(int64_t)r * ld + c];
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) S[(r0 + RSTEP * i) * SLD + c] = v[i];
+}
+
+// NP sub-block updates  A(ib,kb) -= L(ib,jb) L(kb,jb)^T  by one wave: every operand is fetched before the
+// first MFMA and the NP accumulation chains are interleaved.
+template <int NP>
+__device__ inline void update_tiles(double* S, int jb, const int (&ib)[NP], const int (&kb)[NP], const bool (&on)[NP],
+                                    int li, int lg) {
+    d4_t acc[NP];
+    double a[NP][4], b[NP][4];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        if (!on[q]) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[q][r] = S[(ib[q] * JB + lg + 4 * r) * SLD + kb[q] * JB + li];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            a[q][st] = -S[(ib[q] * JB + li) * SLD + jb * JB + 4 * st + lg];
+            b[q][st] = S[(kb[q] * JB + li) * SLD + jb * JB + 4 * st + lg];
         }
     }
-    return ok;
-}
-
-// inverse of the lower-triangular 16 x 16 block whose row r lives in lane r (a[0..15]); rdiag[r] = 1 / a_rr.
-// Lane c (= lane & 15) produces column c of the inverse in w[0..15].  Two partial sums halve the FMA chain.
-__device__ inline void trtri16(const double (&a)[JB], const double (&rdiag)[JB], int c, double (&w)[JB]) {
 #pragma unroll
-    for (int r = 0; r < JB; ++r) {
-        double s0 = 0.0, s1 = 0.0;
+    for (int st = 0; st < 4; ++st) {
 #pragma unroll
-        for (int k = 0; k < r; ++k) {
-            const double lrk = readlane_d(a[k], r);
-            if (k & 1)
-                s1 = fma(lrk, w[k], s1);
-            else
-                s0 = fma(lrk, w[k], s0);
-        }
-        w[r] = (r < c) ? 0.0 : ((r == c ? 1.0 : 0.0) - (s0 + s1)) * rdiag[r];
+        for (int q = 0; q < NP; ++q)
+            if (on[q]) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][st], b[q][st], acc[q], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        if (!on[q]) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(ib[q] * JB + lg + 4 * r) * SLD + kb[q] * JB + li] = acc[q][r];
     }
 }
 
-__device__ inline void recip16(const double (&a)[JB], double (&rdiag)[JB]) {
+// (row, column) of the p-th entry of a lower triangle enumerated row by row
+__constant__ unsigned char TRI_ROW[21] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5};
+__constant__ unsigned char TRI_COL[21] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5};
+
+// Block column jb of the diagonal block: factor its 16 x 16 diagonal sub-block and solve the rows below.
+// Waves 0 and 1 each factor the diagonal sub-block redundantly (see chol16_panel) next to 64 panel rows, so
+// the two instruction streams never have to talk to each other.
+// The diagonal rows (lanes 0..15 of wave 0) stay in a[] on return: the caller stores them after the next
+// barrier, because wave 1 may still be loading the unfactored diagonal sub-block.
+__device__ inline void panel_step(double* S, int jb, int wave, int lane, int32_t* info, int base, int* flag,
+                                  double (&a)[JB]) {
+    const int first = (jb + 1) * JB + wave * 64;  // first panel row of this wave
+    if (wave > 0 && first >= NB) return;
+    const int li = lane & 15;
+    const int row = first + lane;
+    const bool valid = row < NB;
+    const double2* pd = reinterpret_cast<const double2*>(S + (jb * JB + li) * SLD + jb * JB);
+    double2* px = reinterpret_cast<double2*>(S + (valid ? row : jb * JB) * SLD + jb * JB);
+    double x[JB];
 #pragma unroll
-    for (int r = 0; r < JB; ++r) rdiag[r] = 1.0 / readlane_d(a[r], r);
+    for (int k = 0; k < JB / 2; ++k) {
+        const double2 v = pd[k], w = px[k];
+        a[2 * k] = v.x;
+        a[2 * k + 1] = v.y;
+        x[2 * k] = w.x;
+        x[2 * k + 1] = w.y;
+    }
+    bool bad;
+    int bad_col;
+    chol16_panel(a, x, bad, bad_col);
+    if (bad) {
+        if (wave == 0 && lane == 0) {
+            atomicCAS(info, 0, base + jb * JB + bad_col + 1);
+            *flag = 1;
+        }
+        return;
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int k = 0; k < JB / 2; ++k) px[k] = make_double2(x[2 * k], x[2 * k + 1]);
 }
 
-// Given L (lower, in S) and the inverses of its 16x16 diagonal sub-blocks (in Wd), overwrite
-// the strictly-lower sub-blocks of S with those of X = inv(L), block row by block row:
-//   X_ij = -X_ii * sum_{k=j}^{i-1} L_ik X_kj   (row i of L is dead once row i of X is known)
-__device__ inline void block_trtri(double* S, const double* Wd, int nbk, int wave, int nwaves, int li,
-                                   int lg) {
-    for (int i = 1; i < nbk; ++i) {
-        d4_t res = {0, 0, 0, 0};
-        const int j = wave;  // i <= 7 < nwaves: at most one sub-block per wave and block row
-        const bool active = (j < i);
-        if (active) {
-            d4_t acc = {0, 0, 0, 0};
-            for (int k = j; k < i; ++k) {
+// the deferred half of panel_step: L(jb, jb) from the registers of wave 0's diagonal lanes
+__device__ inline void store_diag_rows(double* S, int jb, int lane, const double (&a)[JB]) {
+    double2* p = reinterpret_cast<double2*>(S + (jb * JB + lane) * SLD + jb * JB);
 #pragma unroll
-                for (int st = 0; st < 4; ++st) {
-                    const double a = S[(i * JB + li) * SLD + k * JB + 4 * st + lg];
-                    const double b = (k == j) ? Wd[(j * JB + 4 * st + lg) * WLD + li]
-                                              : S[(k * JB + 4 * st + lg) * SLD + j * JB + li];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-                }
-            }
-            // the D layout (row = lg + 4r) is exactly the B-operand layout of step r
+    for (int k = 0; k < JB / 2; ++k)
+        p[k] = make_double2(2 * k <= lane ? a[2 * k] : 0.0, 2 * k + 1 <= lane ? a[2 * k + 1] : 0.0);
+}
+
+// One 16 x 16 tile of  L21 * X11  (stage 1 of a doubling step), written to the mirror position (j, i) in
+// the unused upper triangle of S.  X11 = inverse of the diagonal block that spans sub-blocks [.., t_end).
+__device__ inline void inv_stage1(double* S, const double* Wd, int i, int j, int t_end, int li, int lg) {
+    d4_t acc = {0, 0, 0, 0};
+    for (int k = j; k < t_end; ++k) {
 #pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const double a = -Wd[(i * JB + li) * WLD + 4 * st + lg];
-                res = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[st], res, 0, 0, 0);
-            }
+        for (int st = 0; st < 4; ++st) {
+            const double a = S[(i * JB + li) * SLD + k * JB + 4 * st + lg];
+            const double b = (k == j) ? Wd[(j * JB + 4 * st + lg) * WLD + li] : S[(k * JB + 4 * st + lg) * SLD + j * JB + li];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
         }
-        __syncthreads();  // every wave has finished reading block row i of L
-        if (active) {
+    }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) S[(i * JB + lg + 4 * r) * SLD + j * JB + li] = res[r];
+    for (int r = 0; r < 4; ++r) S[(j * JB + lg + 4 * r) * SLD + i * JB + li] = acc[r];
+}
+
+// One tile of  X21 = -X22 * (L21 X11)  (stage 2): X22 spans sub-blocks [b0, ..], the product comes from
+// the mirror tiles; the result overwrites L(i, j).
+__device__ inline void inv_stage2(double* S, const double* Wd, int i, int j, int b0, int li, int lg) {
+    d4_t acc = {0, 0, 0, 0};
+    for (int k = b0; k <= i; ++k) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const double a = (k == i) ? Wd[(i * JB + li) * WLD + 4 * st + lg] : S[(i * JB + li) * SLD + k * JB + 4 * st + lg];
+            const double b = S[(j * JB + 4 * st + lg) * SLD + k * JB + li];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a, b, acc, 0, 0, 0);
         }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S[(i * JB + lg + 4 * r) * SLD + j * JB + li] = acc[r];
+}
+
+// Given L (lower, in S) and the inverses of its eight 16 x 16 diagonal sub-blocks (in Wd), overwrite the
+// strictly-lower sub-blocks of S with those of X = inv(L) by recursive doubling:
+//   inv [L11 0; L21 L22] = [X11 0; -X22 L21 X11, X22]       16 -> 32 -> 64 -> 128
+// Five barrier-separated stages; the strict upper triangle of S is scratch.  All 8 waves, block-uniform.
+__device__ inline void block_trtri(double* S, const double* Wd, int wave, int li, int lg) {
+    // 16 -> 32: four pairs, both products in registers (the D layout of the first is the B layout of the second)
+    if (wave < 4) {
+        const int j = 2 * wave, i = j + 1;
+        d4_t acc = {0, 0, 0, 0}, res = {0, 0, 0, 0};
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const double a = S[(i * JB + li) * SLD + j * JB + 4 * st + lg];
+            const double b = Wd[(j * JB + 4 * st + lg) * WLD + li];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const double a = -Wd[(i * JB + li) * WLD + 4 * st + lg];
+            res = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[st], res, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(i * JB + lg + 4 * r) * SLD + j * JB + li] = res[r];
+    }
+    __syncthreads();
+    // 32 -> 64: two pairs x (2 x 2) tiles, one per wave
+    {
+        const int t0 = 4 * (wave >> 2), b0 = t0 + 2;
+        const int i = b0 + ((wave >> 1) & 1), j = t0 + (wave & 1);
+        inv_stage1(S, Wd, i, j, b0, li, lg);
         __syncthreads();
+        inv_stage2(S, Wd, i, j, b0, li, lg);
     }
-    (void)nwaves;
+    __syncthreads();
+    // 64 -> 128: (4 x 4) tiles, two per wave, paired so that every wave sums five sub-block products
+    {
+        const int j = wave & 3, hi = wave >> 2;
+        inv_stage1(S, Wd, 4 + hi, j, 4, li, lg);
+        inv_stage1(S, Wd, 6 + hi, 3 - j, 4, li, lg);
+        __syncthreads();
+        inv_stage2(S, Wd, 4 + hi, j, 4, li, lg);
+        inv_stage2(S, Wd, 7 - hi, j, 4, li, lg);
+    }
+    __syncthreads();
 }
 
-// write inv(L) (diagonal sub-blocks from Wd, strictly-lower ones from S) row-major, ld = NB
-__device__ inline void store_inverse(const double* S, const double* Wd, int n, double* Winv) {
-    for (int idx = threadIdx.x; idx < NB * NB; idx += blockDim.x) {
-        const int r = idx / NB, c = idx - r * NB;
+// write inv(L) (diagonal sub-blocks from Wd, strictly-lower ones from S) row-major, ld = NB; rows >= n are zero
+__device__ inline void store_inverse(const double* S, const double* Wd, int n, double* Winv, int tid) {
+    const int c = tid & (NB - 1), r0 = tid >> 7;
+#pragma unroll 8
+    for (int i = 0; i < NB * NB / DIAG_THREADS; ++i) {
+        const int r = r0 + (DIAG_THREADS / NB) * i;
         double v = 0.0;
-        if (r < n && c <= r) {
-            const int rb = r / JB, cb = c / JB;
-            v = (rb == cb) ? Wd[(rb * JB + (r - rb * JB)) * WLD + (c - cb * JB)] : S[r * SLD + c];
-        }
-        Winv[idx] = v;
+        if (r < n && c <= r) v = ((r ^ c) < JB) ? Wd[r * WLD + (c & (JB - 1))] : S[r * SLD + c];
+        Winv[r * NB + c] = v;
     }
 }
 
-// Factor the n x n (n <= NB) diagonal block A (lower triangle used) in place: on exit the
-// lower triangle holds L, the strict upper triangle is zero; Winv receives inv(L).
-// One workgroup of 8 waves, everything in LDS; sub-block products on the fp64 MFMA.
+#ifdef NPW_DIAG_STAMPS
+__device__ long long* g_diag_stamps = nullptr;
+#endif
+
+// Factor the n x n (n <= NB) diagonal block A (lower triangle used) in place: on exit the lower triangle
+// holds L, the strict upper triangle is zero; Winv receives inv(L).  One workgroup of 8 waves, everything
+// in LDS.  Per 16-wide block column jb the serial chain is only
+//     U_col(jb-1) -> barrier -> chol16 + panel solve (waves 0-1) -> barrier
+// the rest of the rank-16 update (waves 2-6) and the inversion of the finished diagonal sub-block
+// (wave 7) run beside the next column's factorisation (look-ahead inside the workgroup).
 __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(int n, double* A, int64_t lda,
                                                                   int32_t* info, int base, double* Winv) {
     extern __shared__ __attribute__((aligned(16))) double S[];
@@ -166,107 +409,96 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(int n, double*
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    constexpr int NWAVES = DIAG_THREADS / 64;
     const int nbk = (n + JB - 1) / JB;
-    const int npad = nbk * JB;
+#ifdef NPW_DIAG_STAMPS  // developer timing: wall-clock stamps (10 ns units) of the phases, see tools/
+#define NPW_STAMP(i) if (g_diag_stamps && tid == 0) g_diag_stamps[i] = wall_clock64();
+#else
+#define NPW_STAMP(i)
+#endif
+    NPW_STAMP(0)
+#ifdef NPW_DIAG_STAMPS
+    if (g_diag_stamps && tid == 0) g_diag_stamps[22] = clock64();
+#endif
 
-    // lower triangle of A, padded to a multiple of 16 with an identity diagonal
-    for (int idx = tid; idx < npad * npad; idx += DIAG_THREADS) {
-        const int r = idx / npad, c = idx - r * npad;
-        double v = (r == c) ? 1.0 : 0.0;
-        if (r < n && c < n) v = (c <= r) ? A[(int64_t)r * lda + c] : 0.0;
-        S[r * SLD + c] = v;
-    }
+    load_lower_block(S, A, lda, n, tid);
     if (tid == 0) *flag = (*info != 0) ? 1 : 0;
     __syncthreads();
     bool failed = (*flag != 0);  // an earlier block of the same matrix already failed
+    NPW_STAMP(1)
 
-    for (int jb = 0; jb < nbk && !failed; ++jb) {
-        // (1) diagonal sub-block: factor + invert, one wave, registers only
-        if (wave == 0) {
-            double a[JB], w[JB], rdiag[JB];
+    double a[JB];
+    if (!failed) {
+        if (wave < 2) panel_step(S, 0, wave, lane, info, base, flag, a);
+        for (int jb = 0; jb < nbk; ++jb) {
+            __syncthreads();  // column jb is final; all updates of step jb-1 have landed
+            NPW_STAMP(2 + 2 * jb)
+            if (*flag != 0) {
+                failed = true;
+                break;
+            }
+            if (wave == 0 && lane < JB) store_diag_rows(S, jb, lane, a);
+            const int t = nbk - jb - 1;  // sub-block rows below the diagonal one
+            if (wave < t) {              // U_col: block column jb+1 only (t <= 7 tiles, one per wave)
+                const int ib[1] = {jb + 1 + wave}, kb[1] = {jb + 1};
+                const bool on[1] = {true};
+                update_tiles<1>(S, jb, ib, kb, on, li, lg);
+            }
+            __syncthreads();
+            NPW_STAMP(3 + 2 * jb)
+            if (wave < 2) {
+                if (t > 0) panel_step(S, jb + 1, wave, lane, info, base, flag, a);
+            } else if (wave < 7) {       // U_rest: block columns >= jb+2, beside the next panel
+                const int t2 = t - 1, tw = wave - 2;
+                const int npairs = t2 * (t2 + 1) / 2;
+                for (int q0 = 0; q0 < 6 && tw + 5 * q0 < npairs; q0 += 3) {
+                    int ib[3], kb[3];
+                    bool on[3];
 #pragma unroll
-            for (int k = 0; k < JB; ++k) a[k] = S[(jb * JB + li) * SLD + jb * JB + k];
-            int bad_col = 0;
-            const bool ok = chol16(a, rdiag, li, &bad_col);
-            if (!ok) {
-                if (lane == 0) {
-                    atomicCAS(info, 0, base + jb * JB + bad_col + 1);
-                    *flag = 1;
+                    for (int q = 0; q < 3; ++q) {
+                        const int pr = tw + 5 * (q0 + q);
+                        on[q] = pr < npairs;
+                        const int prc = on[q] ? pr : 0;
+                        ib[q] = jb + 2 + TRI_ROW[prc];
+                        kb[q] = jb + 2 + TRI_COL[prc];
+                    }
+                    update_tiles<3>(S, jb, ib, kb, on, li, lg);
                 }
             } else {
-                trtri16(a, rdiag, li, w);
-                if (lane < JB) {
-#pragma unroll
-                    for (int k = 0; k < JB; ++k) {
-                        S[(jb * JB + li) * SLD + jb * JB + k] = (k <= li) ? a[k] : 0.0;
-                        Wd[(jb * JB + k) * WLD + li] = w[k];  // W[r=k][c=li]
-                    }
-                }
+                invert_diag16(S, Wd, jb, lane);
             }
         }
-        __syncthreads();
-        if (*flag != 0) {
-            failed = true;
-            break;
-        }
-        // (2) panel: L_ib = A_ib * inv(L_jj)^T for the sub-blocks below
-        {
-            const int ib = jb + 1 + wave;
-            if (ib < nbk) {
-                double av[4], bv[4];
-#pragma unroll
-                for (int st = 0; st < 4; ++st) {
-                    av[st] = S[(ib * JB + li) * SLD + jb * JB + 4 * st + lg];
-                    bv[st] = Wd[(jb * JB + li) * WLD + 4 * st + lg];  // B[k][c] = W[c][k]
-                }
-                d4_t acc = {0, 0, 0, 0};
-#pragma unroll
-                for (int st = 0; st < 4; ++st) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st], bv[st], acc, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) S[(ib * JB + lg + 4 * r) * SLD + jb * JB + li] = acc[r];
-            }
-        }
-        __syncthreads();
-        // (3) trailing update: A_ik -= L_i L_k^T for jb < kb <= ib
-        {
-            const int t = nbk - jb - 1;
-            const int npairs = t * (t + 1) / 2;
-            for (int pr = wave; pr < npairs; pr += NWAVES) {
-                // unrank pr -> (ii >= kk) in the t x t lower triangle
-                int ii = (int)((sqrtf(8.0f * pr + 1.0f) - 1.0f) * 0.5f);
-                while ((ii + 1) * (ii + 2) / 2 <= pr) ++ii;
-                while (ii * (ii + 1) / 2 > pr) --ii;
-                const int kk = pr - ii * (ii + 1) / 2;
-                const int ib = jb + 1 + ii, kb = jb + 1 + kk;
-                d4_t acc;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = S[(ib * JB + lg + 4 * r) * SLD + kb * JB + li];
-#pragma unroll
-                for (int st = 0; st < 4; ++st) {
-                    const double a = -S[(ib * JB + li) * SLD + jb * JB + 4 * st + lg];
-                    const double b = S[(kb * JB + li) * SLD + jb * JB + 4 * st + lg];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) S[(ib * JB + lg + 4 * r) * SLD + kb * JB + li] = acc[r];
-            }
-        }
-        __syncthreads();
     }
+    __syncthreads();
+    NPW_STAMP(18)
 
     // L back to global: lower triangle, zeros above
-    for (int idx = tid; idx < n * n; idx += DIAG_THREADS) {
-        const int r = idx / n, c = idx - r * n;
-        A[(int64_t)r * lda + c] = (c <= r) ? S[r * SLD + c] : 0.0;
+    {
+        const int c = tid & (NB - 1), r0 = tid >> 7;
+        if (c < n) {
+#pragma unroll 8
+            for (int i = 0; i < NB * NB / DIAG_THREADS; ++i) {
+                const int r = r0 + (DIAG_THREADS / NB) * i;
+                if (r < n) A[(int64_t)r * lda + c] = (c <= r) ? S[r * SLD + c] : 0.0;
+            }
+        }
     }
     if (failed) {
         for (int idx = tid; idx < NB * NB; idx += DIAG_THREADS) Winv[idx] = 0.0;
         return;
     }
+    if (wave >= nbk && lane < JB) {  // identity padding blocks
+#pragma unroll
+        for (int k = 0; k < JB; ++k) Wd[(wave * JB + k) * WLD + li] = (k == li) ? 1.0 : 0.0;
+    }
     __syncthreads();
-    block_trtri(S, Wd, nbk, wave, NWAVES, li, lg);
-    store_inverse(S, Wd, n, Winv);
+    NPW_STAMP(19)
+    block_trtri(S, Wd, wave, li, lg);
+    NPW_STAMP(20)
+    store_inverse(S, Wd, n, Winv, tid);
+    NPW_STAMP(21)
+#ifdef NPW_DIAG_STAMPS
+    if (g_diag_stamps && tid == 0) g_diag_stamps[23] = clock64();
+#endif
 }
 
 // Batched inversion of the NB x NB diagonal blocks of the n x n lower-triangular L:
@@ -278,34 +510,14 @@ __global__ __launch_bounds__(DIAG_THREADS) void trtri_diag_kernel(int n, const d
     const int b = blockIdx.x;
     const int off = b * NB;
     const int nb = min(NB, n - off);
-    const double* Lb = L + (int64_t)off * ldl + off;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lg = lane >> 4;
-    constexpr int NWAVES = DIAG_THREADS / 64;
-    const int nbk = (nb + JB - 1) / JB;
-    const int npad = nbk * JB;
-    for (int idx = tid; idx < npad * npad; idx += DIAG_THREADS) {
-        const int r = idx / npad, c = idx - r * npad;
-        double v = (r == c) ? 1.0 : 0.0;
-        if (r < nb && c < nb) v = (c <= r) ? Lb[(int64_t)r * ldl + c] : 0.0;
-        S[r * SLD + c] = v;
-    }
+    load_lower_block(S, L + (int64_t)off * ldl + off, ldl, nb, tid);
     __syncthreads();
-    for (int jb = wave; jb < nbk; jb += NWAVES) {
-        double a[JB], w[JB], rdiag[JB];
-#pragma unroll
-        for (int k = 0; k < JB; ++k) a[k] = S[(jb * JB + li) * SLD + jb * JB + k];
-        recip16(a, rdiag);
-        trtri16(a, rdiag, li, w);
-        if (lane < JB) {
-#pragma unroll
-            for (int k = 0; k < JB; ++k) Wd[(jb * JB + k) * WLD + li] = w[k];
-        }
-    }
+    invert_diag16(S, Wd, wave, lane);  // 8 waves <-> 8 sub-blocks (identity padding inverts to identity)
     __syncthreads();
-    block_trtri(S, Wd, nbk, wave, NWAVES, li, lg);
-    store_inverse(S, Wd, nb, Winv + (size_t)b * NB * NB);
+    block_trtri(S, Wd, wave, lane & 15, lane >> 4);
+    store_inverse(S, Wd, nb, Winv + (size_t)b * NB * NB, tid);
 }
 
 // dst = lower triangle of src (incl. diagonal), strict upper part = 0
@@ -399,6 +611,36 @@ int potrf_rec(int64_t n, int64_t off, double* A, int64_t lda, int32_t* info, dou
     rc = gemm<double>('N', 'T', n2, n2, n1, -1.0, A21, lda, A21, lda, 1.0, A22, lda, A22, lda, o, s);
     if (rc) return rc;
     return potrf_rec(n2, off + n1, A, lda, info, Winv, T, s);
+}
+
+// Right-looking blocked Cholesky with NB-wide panels: three launches per block column
+//   diag block (factor + invert, one workgroup) -> panel  P <- P inv(L_jj)^T  (in place, one GEMM) ->
+//   trailing update  A22 -= P P^T  (lower tiles only, one GEMM with K = NB).
+// Compared with the recursive form this trades GEMM shape (K = NB updates stream the trailing matrix
+// once per block column: sum ~ n^3 / (3 NB) * 16 B, 1.4 GB for n = 4096) for a third of the launches;
+// a tile is latency-bound on the chain of diagonal blocks, not on flops, so fewer, wider launches win.
+int potrf_right(int64_t n, double* A, int64_t lda, int32_t* info, double* Winv, hipStream_t s) {
+    for (int64_t j0 = 0; j0 < n; j0 += NB) {
+        const int64_t nb = (n - j0 < NB) ? n - j0 : NB;
+        double* Ajj = A + j0 * lda + j0;
+        double* Wj = Winv + (size_t)(j0 / NB) * NB * NB;
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, s, (int)nb, Ajj, lda, info,
+                           (int)j0, Wj);
+        NPW_LAUNCH_CHECK();
+        const int64_t m = n - j0 - nb;
+        if (m == 0) break;
+        double* P = A + (j0 + nb) * lda + j0;
+        GemmOpts o;
+        o.inplace_a = true;
+        int rc = gemm<double>('N', 'T', m, nb, nb, 1.0, P, lda, Wj, NB, 0.0, nullptr, 0, P, lda, o, s);
+        if (rc) return rc;
+        double* A22 = A + (j0 + nb) * lda + (j0 + nb);
+        GemmOpts u;
+        u.lower_only = true;
+        rc = gemm<double>('N', 'T', m, m, nb, -1.0, P, lda, P, lda, 1.0, A22, lda, A22, lda, u, s);
+        if (rc) return rc;
+    }
+    return NPW_OK;
 }
 
 int ensure_big_lds() {
@@ -504,7 +746,21 @@ int npw_dpotrf_lower(int64_t n, const double* A, int64_t lda, double* Lout, int6
     }
     double* Winv = static_cast<double*>(workspace);
     double* T = reinterpret_cast<double*>(static_cast<char*>(workspace) + winv_bytes(n));
-    return potrf_rec(n, 0, Lout, ldl, info_dev, Winv, T, s);
+    static const bool recursive = [] {
+        const char* e = getenv("NPW_POTRF_RECURSIVE");
+        return e && e[0] == '1';
+    }();
+    if (recursive) return potrf_rec(n, 0, Lout, ldl, info_dev, Winv, T, s);
+    return potrf_right(n, Lout, ldl, info_dev, Winv, s);
 }
+
+#ifdef NPW_DIAG_STAMPS
+int npw_debug_diag(double* A, int64_t lda, int32_t* info, double* Winv, long long* stamps) {
+    ensure_big_lds();
+    hipMemcpyToSymbol(HIP_SYMBOL(g_diag_stamps), &stamps, sizeof(stamps));
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, 0, 128, A, lda, info, 0, Winv);
+    return hipDeviceSynchronize() == hipSuccess ? 0 : 1;
+}
+#endif
 
 }  // extern "C"

@@ -115,6 +115,24 @@ __device__ inline void block_to_tile(int tiles_m, int tiles_n, int& tm, int& tn)
     tn = in_band / rows;
 }
 
+// lower-triangle enumeration for square tile grids (BM == BN): the launch holds exactly T (T + 1) / 2
+// workgroups, every XCD gets a contiguous, equally long run of the row-major triangle.  (With the
+// rectangular mapping + early exit the XCD that owns the bottom tile rows does several times the work of
+// the one that owns the top rows, and the launch takes as long as the full square.)
+__device__ inline void block_to_tile_tri(int tiles, int& tm, int& tn) {
+    const int nwg = tiles * (tiles + 1) / 2;
+    const int b = blockIdx.x;
+    constexpr int NXCD = 8;
+    const int q = nwg / NXCD, r = nwg % NXCD;
+    const int xcd = b % NXCD, within = b / NXCD;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    int row = (int)((sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
+    while ((row + 1) * (row + 2) / 2 <= id) ++row;
+    while (row * (row + 1) / 2 > id) --row;
+    tm = row;
+    tn = id - row * (row + 1) / 2;
+}
+
 // TAG only gives the kernel a distinct symbol: TAG 1 = the tile-level trailing update issued by
 // npw_dgemm_nt_sub (kernels.syrk), so profilers report it separately from the many smaller GEMMs that
 // trsm / potrf / geqrt run through the same tiling.
@@ -144,7 +162,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p) {
     constexpr int STAGE = A_ELEMS + B_ELEMS;
 
     int tile_m, tile_n;
-    block_to_tile(p.tiles_m, p.tiles_n, tile_m, tile_n);
+    if (p.lower_only == 2) {
+        block_to_tile_tri(p.tiles_m, tile_m, tile_n);
+    } else {
+        block_to_tile(p.tiles_m, p.tiles_n, tile_m, tile_n);
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     if (p.lower_only && n0 > m0 + BM - 1) return;  // tile entirely above the diagonal
 
@@ -347,7 +369,8 @@ int launch(const GemmParams<T>& p, hipStream_t stream) {
     constexpr int A_ELEMS = A_KC ? BM * LDKC : BK * (BM + 16);
     constexpr int B_ELEMS = B_KC ? BN * LDKC : BK * (BN + 16);
     constexpr size_t smem = 2 * (A_ELEMS + B_ELEMS) * sizeof(T);
-    const int nwg = p.tiles_m * p.tiles_n;
+    // lower_only == 2: only the tiles touching the lower triangle are launched (see block_to_tile_tri)
+    const int nwg = (p.lower_only == 2) ? p.tiles_m * (p.tiles_m + 1) / 2 : p.tiles_m * p.tiles_n;
     const int nsplit = p.k_chunk > 0 ? (p.K + p.k_chunk - 1) / p.k_chunk : 1;
     if constexpr (sizeof(T) == 8 && BM == 128 && BN == 128 && A_KC && B_KC && !EDGE) {
         if (p.tag == 1) {
@@ -456,7 +479,7 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
     p.beta = beta;
     p.skip0 = opts.skip0;
     p.skip1 = opts.skip1;
-    p.lower_only = opts.lower_only ? 1 : 0;
+    p.lower_only = opts.lower_only ? (m == n && !opts.inplace_a ? 2 : 1) : 0;
     p.tag = opts.tag;
     p.k_chunk = opts.k_chunk_;
     p.split_stride = opts.k_chunk_ > 0 ? m * n : 0;

@@ -357,6 +357,30 @@ int main(int argc, char** argv) {
             ms /= reps;
             printf("dgemm %s n=%d: %.3f ms  %.2f TFLOP/s\n", names[v], n, ms, 2.0 * n * n * (double)n / ms / 1e9);
         }
+        if (n >= 4096) {   // latency table for the small products potrf/trsm recursion issues
+            const int shapes[][3] = {{128, 128, 128}, {256, 256, 128}, {256, 256, 256}, {512, 512, 512}, {1024, 1024, 1024},
+                                     {2048, 128, 128}, {4096, 128, 128}, {4096, 256, 256}, {4096, 512, 512},
+                                     {4096, 1024, 1024}, {2048, 2048, 2048}, {4096, 2048, 2048}};
+            for (auto& sh : shapes) {
+                int m = sh[0], nn = sh[1], k = sh[2];
+                for (int v = 0; v < 2; ++v) {
+                    char tb = v ? 'T' : 'N';
+                    for (int w = 0; w < 3; ++w)
+                        CK(npw_dgemm('N', tb, m, nn, k, -1.0, X, n, Y, n, 1.0, S, n, D, n, nullptr, 0));
+                    const int reps = 50;
+                    CK(npw_event_record(e0, 0));
+                    for (int r = 0; r < reps; ++r)
+                        CK(npw_dgemm('N', tb, m, nn, k, -1.0, X, n, Y, n, 1.0, S, n, D, n, nullptr, 0));
+                    CK(npw_event_record(e1, 0));
+                    CK(npw_event_synchronize(e1));
+                    float ms;
+                    CK(npw_event_elapsed_ms(e0, e1, &ms));
+                    ms /= reps;
+                    printf("dgemm N%c %4dx%4dx%4d: %8.2f us  %6.2f TFLOP/s\n", tb, m, nn, k, ms * 1e3,
+                           2.0 * m * nn * (double)k / ms / 1e9);
+                }
+            }
+        }
         {   // potrf / trsm at tile size: A = S S^T/n + n*I built on device
             CK(npw_dgemm('N', 'T', n, n, n, 1.0 / n, S, n, S, n, 0.0, nullptr, n, D, n, nullptr, 0));
             CK(npw_add_diag(D, n, n, n, (double)n, 0));
