@@ -169,7 +169,7 @@ def main():
     for _ in range(args.warmup):
         one_step()
     if world == 1:
-        be.enable_kernel_timers(("syrk", "trsm", "chol"))
+        be.enable_kernel_timers(("syrk", "syrk_sym", "trsm", "chol"))
     barrier()
     t0 = time.time()
     for _ in range(args.steps):

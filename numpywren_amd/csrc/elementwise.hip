@@ -86,24 +86,29 @@ __global__ void init_flag_kernel(int32_t* flag, int32_t v) { *flag = v; }
 
 __global__ void is_zero_kernel(const double* A, int64_t rows, int64_t cols, int64_t lda, double atol,
                                int32_t* flag) {
-    // The answer for a dense tile is known after the first non-zero element: every workgroup polls the
-    // flag (relaxed, L2) once per row and leaves as soon as any workgroup has cleared it, and only waves
-    // that still see it set issue the (contended) atomic -- a dense 128 MiB tile costs a few microseconds
-    // instead of a full sweep plus 32k serialized atomics.
-    bool bad = false;
-    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    // The answer for a dense tile is known after the first non-zero element, so the sweep is built to stop:
+    // a small grid (<= 512 workgroups), every workgroup polls the flag (relaxed, L2) before each batch of
+    // four rows and leaves as soon as anyone has cleared it; a workgroup that finds a non-zero clears the flag
+    // with ONE store, and only if it still reads 1.  (Same-address stores serialise in the L2 channel just
+    // like atomics: one store per wave of a 4096-workgroup grid cost 0.28 ms per dense 4096^2 tile.)
+    constexpr int RB = 4;
+    for (int64_t r0 = (int64_t)blockIdx.y * RB; r0 < rows; r0 += (int64_t)gridDim.y * RB) {
         if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+        bool bad = false;
         for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += (int64_t)gridDim.x * blockDim.x) {
-            const double v = A[r * lda + c];
+            double v[RB];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) v[i] = (r0 + i < rows) ? A[(r0 + i) * lda + c] : 0.0;
             // np.allclose(v, 0): |v - 0| <= atol + rtol*|0|, and non-finite values never match
-            if (!(fabs(v) <= atol)) bad = true;
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+                if (!(fabs(v[i]) <= atol)) bad = true;
         }
-        if (__any(bad)) break;
-    }
-    if (__any(bad)) {
-        // every writer stores the same value, so a plain (relaxed, agent-scope) store is enough: unlike
-        // atomicAnd, same-address stores do not serialise one L2 round trip per wave
-        if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__syncthreads_or(bad)) {
+            if (threadIdx.x == 0 && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
     }
 }
 
@@ -275,8 +280,9 @@ int npw_is_zero(const double* A, int64_t rows, int64_t cols, int64_t lda, double
     NPW_LAUNCH_CHECK();
     if (rows * cols == 0) return NPW_OK;
     NPW_REQUIRE(A != nullptr && lda >= cols, "npw_is_zero: bad arguments");
-    hipLaunchKernelGGL(is_zero_kernel, grid2d(rows, cols), dim3(kThreads), 0, s, A, rows, cols,
-                       lda, atol, flag_dev);
+    dim3 grid = grid2d(rows, cols);
+    if (grid.y > 32) grid.y = 32;
+    hipLaunchKernelGGL(is_zero_kernel, grid, dim3(kThreads), 0, s, A, rows, cols, lda, atol, flag_dev);
     NPW_LAUNCH_CHECK();
     return NPW_OK;
 }

@@ -135,7 +135,7 @@ __device__ inline void block_to_tile_tri(int tiles, int& tm, int& tn) {
 
 // TAG only gives the kernel a distinct symbol: TAG 1 = the tile-level trailing update issued by
 // npw_dgemm_nt_sub (kernels.syrk), so profilers report it separately from the many smaller GEMMs that
-// trsm / potrf / geqrt run through the same tiling.
+// trsm / potrf / geqrt run through the same tiling; TAG 2 = its symmetric form (X == Y, lower tiles only).
 template <typename T, int BM, int BN, int BK, bool A_KC, bool B_KC, bool EDGE, int TAG = 0>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p) {
     using TR = MfmaTraits<T>;
@@ -373,13 +373,14 @@ int launch(const GemmParams<T>& p, hipStream_t stream) {
     const int nwg = (p.lower_only == 2) ? p.tiles_m * (p.tiles_m + 1) / 2 : p.tiles_m * p.tiles_n;
     const int nsplit = p.k_chunk > 0 ? (p.K + p.k_chunk - 1) / p.k_chunk : 1;
     if constexpr (sizeof(T) == 8 && BM == 128 && BN == 128 && A_KC && B_KC && !EDGE) {
-        if (p.tag == 1) {
-            auto tagged = gemm_kernel<T, BM, BN, BK, A_KC, B_KC, EDGE, 1>;
-            static thread_local bool tagged_attr = false;
-            if (!tagged_attr) {
+        if (p.tag == 1 || p.tag == 2) {
+            auto tagged = (p.tag == 1) ? gemm_kernel<T, BM, BN, BK, A_KC, B_KC, EDGE, 1>
+                                       : gemm_kernel<T, BM, BN, BK, A_KC, B_KC, EDGE, 2>;
+            static thread_local bool tagged_attr[3] = {false, false, false};
+            if (!tagged_attr[p.tag]) {
                 NPW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tagged),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                tagged_attr = true;
+                tagged_attr[p.tag] = true;
             }
             hipLaunchKernelGGL(tagged, dim3(nwg, nsplit), dim3(256), smem, stream, p);
             NPW_LAUNCH_CHECK();
@@ -418,6 +419,28 @@ __global__ void splitk_reduce_kernel(int nsplit, const T* P, int64_t stride, int
             if (beta != T(0)) v = fma(beta, C[r * ldc + c], v);
             D[r * ldd + c] = v;
         }
+}
+
+// upper triangle <- transpose of the strictly-lower triangle, 32 x 32 blocks through LDS (both sides coalesced)
+__global__ void mirror_lower_kernel(int64_t n, double* D, int64_t ldd) {
+    __shared__ double tile[32][33];
+    const int64_t nb = (n + 31) / 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int64_t t = blockIdx.x; t < nb * (nb + 1) / 2; t += gridDim.x) {
+        int64_t br = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((br + 1) * (br + 2) / 2 <= t) ++br;
+        while (br * (br + 1) / 2 > t) --br;
+        const int64_t bc = t - br * (br + 1) / 2;  // bc <= br: a block on or below the diagonal
+        const int64_t r0 = br * 32, c0 = bc * 32;
+        __syncthreads();
+        for (int i = ty; i < 32; i += 8)
+            if (r0 + i < n && c0 + tx < n) tile[i][tx] = D[(r0 + i) * ldd + c0 + tx];
+        __syncthreads();
+        for (int i = ty; i < 32; i += 8) {
+            const int64_t r = c0 + i, c = r0 + tx;  // destination element (r, c) = source (c, r)
+            if (r < n && c < n && c > r) D[r * ldd + c] = tile[tx][i];
+        }
+    }
 }
 
 }  // namespace
@@ -561,8 +584,25 @@ int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t l
     o.skip0 = skip_x;
     o.skip1 = skip_y;
     o.tag = 1;
-    return npw::gemm<double>('N', 'T', m, n, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, o,
-                             npw::as_stream(stream));
+    // X == Y (the diagonal tiles of the trailing matrix): X X^T is symmetric bit for bit (element (i, j) and
+    // (j, i) sum the same products in the same order), so only the tiles touching the lower triangle are
+    // computed and the strict upper triangle is filled by transposition.  S is a diagonal tile of a
+    // symmetric matrix here; if its two triangles differ, the lower one wins (as in LAPACK's 'L' routines).
+    const bool sym = (X == Y && ldx == ldy && m == n && m >= 256 && k > 0);
+    if (!sym)
+        return npw::gemm<double>('N', 'T', m, n, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, o,
+                                 npw::as_stream(stream));
+    o.tag = 2;
+    o.lower_only = true;
+    int rc = npw::gemm<double>('N', 'T', m, n, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, o,
+                               npw::as_stream(stream));
+    if (rc) return rc;
+    const int64_t nb = (n + 31) / 32;
+    const int64_t tiles = nb * (nb + 1) / 2;
+    hipLaunchKernelGGL(npw::mirror_lower_kernel, dim3((unsigned)(tiles < 8192 ? tiles : 8192)), dim3(256), 0,
+                       npw::as_stream(stream), n, D, ldd);
+    NPW_LAUNCH_CHECK();
+    return NPW_OK;
 }
 
 }  // extern "C"
