@@ -86,10 +86,12 @@ struct GemmParams {
     const int32_t* skip0;
     const int32_t* skip1;
     int tiles_m, tiles_n;
-    int lower_only;
+    int tiles_batch;
+    int lower_only;  // 0 all tiles | 1 rectangular grid, early exit above the diagonal | 2 lower triangle | 3 strictly lower
     int tag;
     int k_chunk;           // split-K: k range handled per blockIdx.y (0 = no split)
     int64_t split_stride;  // split-K: element stride between the partial outputs
+    int64_t batch_a, batch_b, batch_c, batch_d;  // element strides between the problems of a batch (blockIdx.z)
 };
 
 // XCD-aware + grouped mapping of the linear block id to an output tile.
@@ -137,7 +139,15 @@ __device__ inline void block_to_tile_tri(int tiles, int& tm, int& tn) {
 // npw_dgemm_nt_sub (kernels.syrk), so profilers report it separately from the many smaller GEMMs that
 // trsm / potrf / geqrt run through the same tiling; TAG 2 = its symmetric form (X == Y, lower tiles only).
 template <typename T, int BM, int BN, int BK, bool A_KC, bool B_KC, bool EDGE, int TAG = 0>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) {
+    GemmParams<T> p = p_in;
+    if (gridDim.z > 1) {
+        const int64_t bz = blockIdx.z;
+        p.A += bz * p.batch_a;
+        p.B += bz * p.batch_b;
+        if (p.C) p.C += bz * p.batch_c;
+        p.D += bz * p.batch_d;
+    }
     using TR = MfmaTraits<T>;
     using acc_t = typename TR::acc_t;
     using vec_t = typename TR::vec_t;
@@ -164,6 +174,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p) {
     int tile_m, tile_n;
     if (p.lower_only == 2) {
         block_to_tile_tri(p.tiles_m, tile_m, tile_n);
+    } else if (p.lower_only == 3) {  // strictly lower tiles: the triangle of order tiles - 1, one row down
+        block_to_tile_tri(p.tiles_m - 1, tile_m, tile_n);
+        tile_m += 1;
     } else {
         block_to_tile(p.tiles_m, p.tiles_n, tile_m, tile_n);
     }
@@ -370,7 +383,11 @@ int launch(const GemmParams<T>& p, hipStream_t stream) {
     constexpr int B_ELEMS = B_KC ? BN * LDKC : BK * (BN + 16);
     constexpr size_t smem = 2 * (A_ELEMS + B_ELEMS) * sizeof(T);
     // lower_only == 2: only the tiles touching the lower triangle are launched (see block_to_tile_tri)
-    const int nwg = (p.lower_only == 2) ? p.tiles_m * (p.tiles_m + 1) / 2 : p.tiles_m * p.tiles_n;
+    const int nwg = (p.lower_only == 2)   ? p.tiles_m * (p.tiles_m + 1) / 2
+                    : (p.lower_only == 3) ? p.tiles_m * (p.tiles_m - 1) / 2
+                                          : p.tiles_m * p.tiles_n;
+    if (nwg == 0) return NPW_OK;
+    const unsigned nbatch = (unsigned)p.tiles_batch;
     const int nsplit = p.k_chunk > 0 ? (p.K + p.k_chunk - 1) / p.k_chunk : 1;
     if constexpr (sizeof(T) == 8 && BM == 128 && BN == 128 && A_KC && B_KC && !EDGE) {
         if (p.tag == 1 || p.tag == 2) {
@@ -382,7 +399,7 @@ int launch(const GemmParams<T>& p, hipStream_t stream) {
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
                 tagged_attr[p.tag] = true;
             }
-            hipLaunchKernelGGL(tagged, dim3(nwg, nsplit), dim3(256), smem, stream, p);
+            hipLaunchKernelGGL(tagged, dim3(nwg, nsplit, nbatch), dim3(256), smem, stream, p);
             NPW_LAUNCH_CHECK();
             return NPW_OK;
         }
@@ -394,7 +411,7 @@ int launch(const GemmParams<T>& p, hipStream_t stream) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(nwg, nsplit), dim3(256), smem, stream, p);
+    hipLaunchKernelGGL(kern, dim3(nwg, nsplit, nbatch), dim3(256), smem, stream, p);
     NPW_LAUNCH_CHECK();
     return NPW_OK;
 }
@@ -502,7 +519,14 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
     p.beta = beta;
     p.skip0 = opts.skip0;
     p.skip1 = opts.skip1;
-    p.lower_only = opts.lower_only ? (m == n && !opts.inplace_a ? 2 : 1) : 0;
+    p.lower_only = opts.lower_only ? (m == n && !opts.inplace_a ? (opts.strict_lower ? 3 : 2) : 1) : 0;
+    NPW_REQUIRE(!opts.strict_lower || p.lower_only == 3, "gemm: strict_lower needs a square lower_only product");
+    NPW_REQUIRE(opts.batch >= 1 && (opts.batch == 1 || opts.k_chunk_ == 0), "gemm: bad batch");
+    p.tiles_batch = opts.batch;
+    p.batch_a = opts.batch_a;
+    p.batch_b = opts.batch_b;
+    p.batch_c = opts.batch_c;
+    p.batch_d = opts.batch_d;
     p.tag = opts.tag;
     p.k_chunk = opts.k_chunk_;
     p.split_stride = opts.k_chunk_ > 0 ? m * n : 0;
@@ -594,8 +618,26 @@ int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t l
                                  npw::as_stream(stream));
     o.tag = 2;
     o.lower_only = true;
-    int rc = npw::gemm<double>('N', 'T', m, n, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, o,
-                               npw::as_stream(stream));
+    int rc;
+    if (m % 128 == 0 && m >= 2048) {
+        // 2 workgroups share a CU, so the chip holds 512 tiles at a time: the 496 strictly-lower tiles of a
+        // 4096^2 output are one full wave of work, the 32 diagonal tiles would be a second, nearly empty one.
+        // They go into their own small batched launch (lower 64 x 64 sub-tiles only) instead.
+        o.strict_lower = true;
+        rc = npw::gemm<double>('N', 'T', m, n, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, o, npw::as_stream(stream));
+        if (rc) return rc;
+        npw::GemmOpts d;
+        d.skip0 = skip_x;
+        d.skip1 = skip_y;
+        d.lower_only = true;
+        d.batch = (int)(m / 128);
+        d.batch_a = d.batch_b = 128 * ldx;
+        d.batch_c = 128 * (lds + 1);
+        d.batch_d = 128 * (ldd + 1);
+        rc = npw::gemm<double>('N', 'T', 128, 128, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, d, npw::as_stream(stream));
+    } else {
+        rc = npw::gemm<double>('N', 'T', m, n, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, o, npw::as_stream(stream));
+    }
     if (rc) return rc;
     const int64_t nb = (n + 31) / 32;
     const int64_t tiles = nb * (nb + 1) / 2;

@@ -51,6 +51,9 @@ struct GemmOpts {
     int splitk = 1;           // > 1 with splitk_ws: cut k into this many chunks (skinny outputs, long k)
     void* splitk_ws = nullptr;  // splitk * m * n elements of scratch
     int k_chunk_ = 0;         // internal: k range per blockIdx.y of the partial-product launch
+    bool strict_lower = false;  // with lower_only on a square output: skip the diagonal tiles as well
+    int batch = 1;            // > 1: blockIdx.z walks `batch` problems, operand b at base + b * batch_x elements
+    int64_t batch_a = 0, batch_b = 0, batch_c = 0, batch_d = 0;
 };
 
 // D = alpha * op(A) op(B) + beta * C

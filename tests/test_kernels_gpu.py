@@ -101,6 +101,25 @@ def test_cholesky_chain_vs_oracle(b):
     np.testing.assert_allclose(kernels.syrk(S, X, Y), oracle.syrk(S, X, Y), rtol=0, atol=1e-12 * b)
 
 
+@pytest.mark.parametrize("n,k", [(256, 96), (384, 64), (2048, 128), (2176, 64)])
+def test_syrk_same_operand_is_bitwise_the_full_product(n, k):
+    """x is y (diagonal tiles of the trailing matrix): lower tiles + mirror == the full S - X Y^T, bit for bit."""
+    from numpywren_amd.device import get_backend
+    be = get_backend()
+    rng = np.random.default_rng(n + k)
+    Xh = rng.standard_normal((n, k))
+    G = rng.standard_normal((n, n))
+    Sh = G + G.T
+    S, X, Xc = be.to_device(Sh), be.to_device(Xh), be.to_device(Xh)
+    sym = be.to_host(be.syrk(S, X, X))
+    full = be.to_host(be.syrk(S, X, Xc))          # distinct buffers -> general path
+    assert np.array_equal(sym, full)
+    assert np.array_equal(sym, sym.T)
+    np.testing.assert_allclose(sym, oracle.syrk(Sh, Xh, Xh), rtol=0, atol=1e-12 * k)
+    z = be.zeros((n, k))                            # allclose(x, 0) short-circuit keeps s
+    assert np.array_equal(be.to_host(be.syrk(S, z, z)), Sh)
+
+
 def test_chol_not_positive_definite():
     A = np.eye(40)
     A[17, 17] = -1.0
