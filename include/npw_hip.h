@@ -138,9 +138,10 @@ int npw_dtrsm_rltn(int64_t m, int64_t n, const double* L, int64_t ldl, const dou
 /* The same solve split in two so that the many trsm tasks of one Cholesky step, which share
  * the same L (reference numpywren/algs.py:243-246: O[j,i] = trsm(O[i,i], S[i,j,i]) for all j),
  * invert its diagonal blocks once:
- *   npw_dtrtri_diag      Winv <- inverses of the 128 x 128 diagonal blocks of the n x n lower
- *                        triangular L (block b at Winv + b*128*128, row-major, ld 128);
- *                        Winv has npw_dtrtri_diag_bytes(n) bytes.
+ *   npw_dtrtri_diag      Winv <- inverses of the diagonal blocks of the n x n lower triangular L
+ *                        (the 512 x 512 diagonal blocks; 128 x 128 ones in a ragged tail).  The
+ *                        layout is private to the library: callers only size it with
+ *                        npw_dtrtri_diag_bytes(n) and hand it to npw_dtrsm_rltn_inv.
  *   npw_dtrsm_rltn_inv   X = B * L^-T using those inverses; workspace:
  *                        npw_dtrsm_rltn_inv_workspace_bytes(m, n) bytes.
  * npw_dpotrf_lower leaves exactly such a Winv in the first npw_dtrtri_diag_bytes(n) bytes of

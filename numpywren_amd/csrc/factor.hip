@@ -34,6 +34,13 @@ constexpr int S_ELEMS = NB * SLD;
 constexpr int W_ELEMS = NJB * JB * WLD;
 constexpr size_t DIAG_LDS_BYTES = (size_t)(S_ELEMS + W_ELEMS + 2) * sizeof(double);  // 150,544 B
 constexpr int DIAG_THREADS = 512;
+// The inverses of L's diagonal blocks ("Winv") live in groups of LW x LW (row-major, ld = LW): group g covers
+// the diagonal blocks 4g .. 4g+3 of size NB at (q NB, q NB) inside it.  The diagonal kernels fill the NB x NB
+// blocks; complete_groups() then fills the rest of the lower triangle of every *full* group, so a group
+// is inv(L[g LW : (g+1) LW, same]) and the solve can use LW-wide leaves.  Everything above the diagonal is
+// zero (memset once).  After the groups comes scratch for complete_groups (LW/2 x LW/2 per group).
+constexpr int LW = 512;
+constexpr int WPG = LW / NB;  // diagonal blocks per group
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
@@ -379,7 +386,11 @@ __device__ inline void block_trtri(double* S, const double* Wd, int wave, int li
     __syncthreads();
 }
 
-// write inv(L) (diagonal sub-blocks from Wd, strictly-lower ones from S) row-major, ld = NB; rows >= n are zero
+__host__ __device__ inline size_t w_block_offset(int64_t b) {  // element offset of diagonal block b inside Winv
+    return (size_t)(b / WPG) * LW * LW + (size_t)(b % WPG) * NB * (LW + 1);
+}
+
+// write inv(L) (diagonal sub-blocks from Wd, strictly-lower ones from S) row-major, ld = LW; rows >= n are zero
 __device__ inline void store_inverse(const double* S, const double* Wd, int n, double* Winv, int tid) {
     const int c = tid & (NB - 1), r0 = tid >> 7;
 #pragma unroll 8
@@ -387,7 +398,7 @@ __device__ inline void store_inverse(const double* S, const double* Wd, int n, d
         const int r = r0 + (DIAG_THREADS / NB) * i;
         double v = 0.0;
         if (r < n && c <= r) v = ((r ^ c) < JB) ? Wd[r * WLD + (c & (JB - 1))] : S[r * SLD + c];
-        Winv[r * NB + c] = v;
+        Winv[r * LW + c] = v;
     }
 }
 
@@ -483,7 +494,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(int n, double*
         }
     }
     if (failed) {
-        for (int idx = tid; idx < NB * NB; idx += DIAG_THREADS) Winv[idx] = 0.0;
+        for (int idx = tid; idx < NB * NB; idx += DIAG_THREADS) Winv[(idx / NB) * LW + (idx % NB)] = 0.0;
         return;
     }
     if (wave >= nbk && lane < JB) {  // identity padding blocks
@@ -502,7 +513,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(int n, double*
 }
 
 // Batched inversion of the NB x NB diagonal blocks of the n x n lower-triangular L:
-// block b -> Winv + b * NB * NB.
+// block b -> Winv + w_block_offset(b), ld = LW.
 __global__ __launch_bounds__(DIAG_THREADS) void trtri_diag_kernel(int n, const double* L, int64_t ldl,
                                                                   double* Winv) {
     extern __shared__ __attribute__((aligned(16))) double S[];
@@ -517,7 +528,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void trtri_diag_kernel(int n, const d
     invert_diag16(S, Wd, wave, lane);  // 8 waves <-> 8 sub-blocks (identity padding inverts to identity)
     __syncthreads();
     block_trtri(S, Wd, wave, lane & 15, lane >> 4);
-    store_inverse(S, Wd, nb, Winv + (size_t)b * NB * NB, tid);
+    store_inverse(S, Wd, nb, Winv + w_block_offset(b), tid);
 }
 
 // dst = lower triangle of src (incl. diagonal), strict upper part = 0
@@ -537,7 +548,50 @@ inline int64_t split(int64_t n) {  // first-half size: multiple of NB, roughly n
     return (blocks / 2) * NB;
 }
 
-inline size_t winv_bytes(int64_t n) { return (size_t)ceil_div(n, NB) * NB * NB * sizeof(double); }
+inline size_t winv_group_elems(int64_t n) { return (size_t)ceil_div(n, LW) * LW * LW; }
+inline size_t winv_bytes(int64_t n) {
+    return (winv_group_elems(n) + (size_t)ceil_div(n, LW) * (LW / 2) * (LW / 2)) * sizeof(double);
+}
+
+// Fill the off-diagonal part of every full LW x LW group of Winv by two doubling steps (batched GEMMs):
+//   inv [L11 0; L21 L22] = [X11 0; -X22 L21 X11, X22]     NB -> 2 NB (two pairs per group) -> LW
+// Zeroes Winv's groups first?  No: the caller memsets before the diagonal kernels run.
+int complete_groups(int64_t n, const double* L, int64_t ldl, double* Winv, hipStream_t s) {
+    const int groups = (int)(n / LW);  // full groups only; a ragged tail keeps NB-wide leaves
+    if (groups == 0) return NPW_OK;
+    double* T = Winv + winv_group_elems(n);
+    const int64_t tstride = (LW / 2) * (LW / 2);
+    for (int half = NB; half < LW; half *= 2) {
+        const int pairs = LW / (2 * half);  // pairs per group
+        GemmOpts o;
+        o.batch = groups * pairs;
+        o.batch_inner = pairs;
+        // T = L21 * X11      (half x half each, problem (g, h))
+        o.batch_a = (int64_t)LW * (ldl + 1);
+        o.batch2_a = (int64_t)2 * half * (ldl + 1);
+        o.batch_b = (int64_t)LW * LW;
+        o.batch2_b = (int64_t)2 * half * (LW + 1);
+        o.batch_d = tstride;
+        o.batch2_d = (int64_t)half * half;
+        int rc = gemm<double>('N', 'N', half, half, half, 1.0, L + (int64_t)half * ldl, ldl, Winv, LW, 0.0, nullptr, 0, T,
+                              half, o, s);
+        if (rc) return rc;
+        // X21 = -X22 * T
+        GemmOpts q;
+        q.batch = o.batch;
+        q.batch_inner = pairs;
+        q.batch_a = (int64_t)LW * LW;
+        q.batch2_a = (int64_t)2 * half * (LW + 1);
+        q.batch_b = tstride;
+        q.batch2_b = (int64_t)half * half;
+        q.batch_d = (int64_t)LW * LW;
+        q.batch2_d = (int64_t)2 * half * (LW + 1);
+        rc = gemm<double>('N', 'N', half, half, half, -1.0, Winv + (int64_t)half * (LW + 1), LW, T, half, 0.0, nullptr, 0,
+                          Winv + (int64_t)half * LW, LW, q, s);
+        if (rc) return rc;
+    }
+    return NPW_OK;
+}
 
 // State of one triangular solve  X * L^T = B  (X, B: m x n).
 //   Winv : inverses of L's NB x NB diagonal blocks (block index = absolute column offset / NB)
@@ -557,22 +611,25 @@ struct TrsmCtx {
     const double* Winv;
     int64_t c0;  // absolute column offset of X's / B's / T's column 0 inside L (potrf panels)
     hipStream_t s;
+    bool groups_ready = false;  // Winv's full LW groups are complete inverses (complete_groups ran)
 };
 
 // solve the column range [coff, coff + n) (relative to the panel); `touched`: its current values are in T
 int trsm_rec(const TrsmCtx& c, int64_t coff, int64_t n, bool touched) {
-    if (n <= NB) {
-        const double* Wb = c.Winv + (size_t)((c.c0 + coff) / NB) * NB * NB;
+    const int64_t col = c.c0 + coff;  // absolute column inside L
+    const bool group_leaf = (n == LW && col % LW == 0 && c.groups_ready);
+    if (n <= NB || group_leaf) {
+        const double* Wb = group_leaf ? c.Winv + (size_t)(col / LW) * LW * LW : c.Winv + w_block_offset(col / NB);
         double* Xj = c.X + coff;
+        GemmOpts o;
+        o.b_lower_tri = group_leaf;  // inv(L_group) is lower triangular: column tile n0 stops at k = n0 + BN
         if (touched)
-            return gemm<double>('N', 'T', c.m, n, n, 1.0, c.T + coff, c.ldt, Wb, NB, 0.0, nullptr, 0, Xj, c.ldx,
-                                GemmOpts(), c.s);
+            return gemm<double>('N', 'T', c.m, n, n, 1.0, c.T + coff, c.ldt, Wb, LW, 0.0, nullptr, 0, Xj, c.ldx, o, c.s);
         if ((const void*)c.B != (const void*)c.X)
-            return gemm<double>('N', 'T', c.m, n, n, 1.0, c.B + coff, c.ldb, Wb, NB, 0.0, nullptr, 0, Xj, c.ldx,
-                                GemmOpts(), c.s);
-        GemmOpts o;  // in-place solve of the first block of an in-place panel (row-panel tiling)
-        o.inplace_a = true;
-        return gemm<double>('N', 'T', c.m, n, n, 1.0, Xj, c.ldx, Wb, NB, 0.0, nullptr, 0, Xj, c.ldx, o, c.s);
+            return gemm<double>('N', 'T', c.m, n, n, 1.0, c.B + coff, c.ldb, Wb, LW, 0.0, nullptr, 0, Xj, c.ldx, o, c.s);
+        NPW_REQUIRE(!group_leaf, "trsm: in-place panels use NB-wide leaves");
+        o.inplace_a = true;  // in-place solve of the first block of an in-place panel (row-panel tiling)
+        return gemm<double>('N', 'T', c.m, n, n, 1.0, Xj, c.ldx, Wb, LW, 0.0, nullptr, 0, Xj, c.ldx, o, c.s);
     }
     const int64_t n1 = split(n), n2 = n - n1;
     int rc = trsm_rec(c, coff, n1, touched);
@@ -592,7 +649,7 @@ int potrf_rec(int64_t n, int64_t off, double* A, int64_t lda, int32_t* info, dou
     double* Ab = A + off * lda + off;
     if (n <= NB) {
         hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, s, (int)n, Ab, lda, info,
-                           (int)off, Winv + (size_t)(off / NB) * NB * NB);
+                           (int)off, Winv + w_block_offset(off / NB));
         NPW_LAUNCH_CHECK();
         return NPW_OK;
     }
@@ -623,7 +680,7 @@ int potrf_right(int64_t n, double* A, int64_t lda, int32_t* info, double* Winv, 
     for (int64_t j0 = 0; j0 < n; j0 += NB) {
         const int64_t nb = (n - j0 < NB) ? n - j0 : NB;
         double* Ajj = A + j0 * lda + j0;
-        double* Wj = Winv + (size_t)(j0 / NB) * NB * NB;
+        double* Wj = Winv + w_block_offset(j0 / NB);
         hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, s, (int)nb, Ajj, lda, info,
                            (int)j0, Wj);
         NPW_LAUNCH_CHECK();
@@ -632,7 +689,7 @@ int potrf_right(int64_t n, double* A, int64_t lda, int32_t* info, double* Winv, 
         double* P = A + (j0 + nb) * lda + j0;
         GemmOpts o;
         o.inplace_a = true;
-        int rc = gemm<double>('N', 'T', m, nb, nb, 1.0, P, lda, Wj, NB, 0.0, nullptr, 0, P, lda, o, s);
+        int rc = gemm<double>('N', 'T', m, nb, nb, 1.0, P, lda, Wj, LW, 0.0, nullptr, 0, P, lda, o, s);
         if (rc) return rc;
         double* A22 = A + (j0 + nb) * lda + (j0 + nb);
         GemmOpts u;
@@ -671,10 +728,11 @@ int npw_dtrtri_diag(int64_t n, const double* L, int64_t ldl, double* Winv, npw_s
     int rc = ensure_big_lds();
     if (rc) return rc;
     const int nblk = (int)ceil_div(n, NB);
-    hipLaunchKernelGGL(trtri_diag_kernel, dim3(nblk), dim3(DIAG_THREADS), DIAG_LDS_BYTES, as_stream(stream), (int)n, L,
-                       ldl, Winv);
+    hipStream_t s = as_stream(stream);
+    NPW_HIP_CHECK(hipMemsetAsync(Winv, 0, winv_group_elems(n) * sizeof(double), s));
+    hipLaunchKernelGGL(trtri_diag_kernel, dim3(nblk), dim3(DIAG_THREADS), DIAG_LDS_BYTES, s, (int)n, L, ldl, Winv);
     NPW_LAUNCH_CHECK();
-    return NPW_OK;
+    return complete_groups(n, L, ldl, Winv, s);
 }
 
 size_t npw_dtrsm_rltn_inv_workspace_bytes(int64_t m, int64_t n) {
@@ -696,6 +754,7 @@ int npw_dtrsm_rltn_inv(int64_t m, int64_t n, const double* L, int64_t ldl, const
                     "npw_dtrsm_rltn_inv: X and B overlap without being identical");
     }
     TrsmCtx c{m, L, ldl, B, ldb, X, ldx, static_cast<double*>(workspace), n, Winv, 0, as_stream(stream)};
+    c.groups_ready = true;  // Winv comes from npw_dtrtri_diag or npw_dpotrf_lower, which both complete the groups
     return trsm_rec(c, 0, n, false);
 }
 
@@ -750,8 +809,10 @@ int npw_dpotrf_lower(int64_t n, const double* A, int64_t lda, double* Lout, int6
         const char* e = getenv("NPW_POTRF_RECURSIVE");
         return e && e[0] == '1';
     }();
-    if (recursive) return potrf_rec(n, 0, Lout, ldl, info_dev, Winv, T, s);
-    return potrf_right(n, Lout, ldl, info_dev, Winv, s);
+    NPW_HIP_CHECK(hipMemsetAsync(Winv, 0, winv_group_elems(n) * sizeof(double), s));
+    rc = recursive ? potrf_rec(n, 0, Lout, ldl, info_dev, Winv, T, s) : potrf_right(n, Lout, ldl, info_dev, Winv, s);
+    if (rc) return rc;
+    return complete_groups(n, Lout, ldl, Winv, s);  // the factor's trsm consumers use LW-wide leaves
 }
 
 #ifdef NPW_DIAG_STAMPS

@@ -92,6 +92,9 @@ struct GemmParams {
     int k_chunk;           // split-K: k range handled per blockIdx.y (0 = no split)
     int64_t split_stride;  // split-K: element stride between the partial outputs
     int64_t batch_a, batch_b, batch_c, batch_d;  // element strides between the problems of a batch (blockIdx.z)
+    int batch_inner;                                  // two-level batch: z -> (z / inner, z % inner)
+    int64_t batch2_a, batch2_b, batch2_c, batch2_d;
+    int b_lower_tri;                                  // k range of column tile n0 ends at n0 + BN
 };
 
 // XCD-aware + grouped mapping of the linear block id to an output tile.
@@ -142,11 +145,15 @@ template <typename T, int BM, int BN, int BK, bool A_KC, bool B_KC, bool EDGE, i
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) {
     GemmParams<T> p = p_in;
     if (gridDim.z > 1) {
-        const int64_t bz = blockIdx.z;
-        p.A += bz * p.batch_a;
-        p.B += bz * p.batch_b;
-        if (p.C) p.C += bz * p.batch_c;
-        p.D += bz * p.batch_d;
+        int64_t bz = blockIdx.z, b2 = 0;
+        if (p.batch_inner > 0) {
+            b2 = bz % p.batch_inner;
+            bz = bz / p.batch_inner;
+        }
+        p.A += bz * p.batch_a + b2 * p.batch2_a;
+        p.B += bz * p.batch_b + b2 * p.batch2_b;
+        if (p.C) p.C += bz * p.batch_c + b2 * p.batch2_c;
+        p.D += bz * p.batch_d + b2 * p.batch2_d;
     }
     using TR = MfmaTraits<T>;
     using acc_t = typename TR::acc_t;
@@ -191,7 +198,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
 
     // split-K: blockIdx.y selects the k range [kb, kend) and its own partial output
     const int kb = p.k_chunk > 0 ? (int)blockIdx.y * p.k_chunk : 0;
-    const int kend = p.k_chunk > 0 ? min(p.K, kb + p.k_chunk) : p.K;
+    int kend = p.k_chunk > 0 ? min(p.K, kb + p.k_chunk) : p.K;
+    if (p.b_lower_tri) kend = min(kend, n0 + BN);  // rows of W^T below the diagonal block are zero
     int nk = (kend - kb + BK - 1) / BK;
     if ((p.skip0 && *p.skip0) || (p.skip1 && *p.skip1)) nk = 0;
 
@@ -527,6 +535,12 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
     p.batch_b = opts.batch_b;
     p.batch_c = opts.batch_c;
     p.batch_d = opts.batch_d;
+    p.batch_inner = opts.batch_inner;
+    p.batch2_a = opts.batch2_a;
+    p.batch2_b = opts.batch2_b;
+    p.batch2_c = opts.batch2_c;
+    p.batch2_d = opts.batch2_d;
+    p.b_lower_tri = opts.b_lower_tri ? 1 : 0;
     p.tag = opts.tag;
     p.k_chunk = opts.k_chunk_;
     p.split_stride = opts.k_chunk_ > 0 ? m * n : 0;

@@ -54,6 +54,9 @@ struct GemmOpts {
     bool strict_lower = false;  // with lower_only on a square output: skip the diagonal tiles as well
     int batch = 1;            // > 1: blockIdx.z walks `batch` problems, operand b at base + b * batch_x elements
     int64_t batch_a = 0, batch_b = 0, batch_c = 0, batch_d = 0;
+    int batch_inner = 0;      // > 0: two-level batch, problem z = (z / inner) * batch_x + (z % inner) * batch2_x
+    int64_t batch2_a = 0, batch2_b = 0, batch2_c = 0, batch2_d = 0;
+    bool b_lower_tri = false;  // op(B) = W^T with W (n x k) lower triangular: column tile n0 only needs k < n0 + BN
 };
 
 // D = alpha * op(A) op(B) + beta * C
