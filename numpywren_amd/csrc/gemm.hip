@@ -568,8 +568,17 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
         return dispatch_layout<T, 64, 128, BKS, true>(a_kc, b_kc, p, stream);
     }
     // tile selection: 128x128 when it fills the chip (or the problem is large), else 64x64
-    const int64_t wg128 = ceil_div(m, 128) * ceil_div(n, 128);
-    const bool big = (wg128 >= 192);
+    const int64_t t128 = ceil_div(m, 128);
+    const int64_t wg128 = (p.lower_only >= 2) ? t128 * (t128 + 1) / 2 : t128 * ceil_div(n, 128);
+    static const int64_t big_min = [] {
+        const char* e = getenv("NPW_GEMM_BIG_MIN");
+        return e ? (int64_t)atoi(e) : (int64_t)192;
+    }();
+    static const int64_t big_min_shortk = [] {
+        const char* e = getenv("NPW_GEMM_BIG_MIN_SHORTK");
+        return e ? (int64_t)atoi(e) : (int64_t)512;  // k <= 256: prologue/epilogue-bound, more workgroups win
+    }();
+    const bool big = (wg128 >= (k <= 256 ? big_min_shortk : big_min));
     if (big) {
         p.tiles_m = (int)ceil_div(m, 128);
         p.tiles_n = (int)ceil_div(n, 128);

@@ -11,7 +11,7 @@ i0 = starts[-1]
 seq = []
 for r in rows[i0:]:
     name = r["Kernel_Name"]
-    if seq and not any(k in name for k in ("gemm", "potrf_diag", "splitk")):
+    if seq and not any(k in name for k in ("gemm", "potrf_diag", "potrf_panel", "splitk", "fillBuffer")):
         break
     seq.append(r)
 t0 = int(seq[0]["Start_Timestamp"])
@@ -20,7 +20,7 @@ tot = {}
 for k, r in enumerate(seq):
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     name = r["Kernel_Name"]
-    short = "diag" if "potrf_diag" in name else ("tril" if "tril" in name else "gemm")
+    short = "diag" if ("potrf_diag" in name or "potrf_panel" in name) else ("tril" if "tril" in name else ("fill" if "fillBuffer" in name else "gemm"))
     g = f'{r.get("Grid_Size_X", r.get("Grid_Size", "?"))}/{r.get("Workgroup_Size_X", r.get("Workgroup_Size", "?"))}'
     d = tot.setdefault(short, [0, 0.0, 0.0])
     d[0] += 1
