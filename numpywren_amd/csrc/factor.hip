@@ -44,12 +44,6 @@ constexpr int WPG = LW / NB;  // diagonal blocks per group
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
-__device__ inline double readlane_d(double x, int src_lane) {  // src_lane must be wave-uniform
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_readlane(lo, src_lane);
-    hi = __builtin_amdgcn_readlane(hi, src_lane);
-    return __hiloint2double(hi, lo);
-}
 
 // ---- cross-lane arithmetic inside a row of 16 lanes (DPP row_newbcast: every lane of the row reads lane K) ----
 // gfx950 offers DPP on the 64-bit ALU only for v_fmac / v_mov (v_rsq_f64_dpp assembles but returns garbage on
