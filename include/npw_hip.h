@@ -119,6 +119,9 @@ int npw_sgemm(char transA, char transB, int64_t m, int64_t n, int64_t k, float a
 
 /* D = S - X * Y^T   (S,D: m x n; X: m x k; Y: n x k).  D may alias S.
  * skip_x / skip_y: optional device flags (see npw_is_zero): if either is set D = S.
+ * X == Y (same pointer and ld, m == n >= 256: the diagonal tiles of the trailing matrix): X X^T is
+ * symmetric bit for bit, so only the tiles touching the lower triangle are computed and the strict
+ * upper triangle of D is their transpose; S is then assumed symmetric (its lower triangle wins).
  * Replaces kernels.syrk (reference numpywren/kernels.py:212-215) -- the Cholesky
  * trailing update, the north-star kernel.                                      */
 int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t lds,
@@ -216,6 +219,13 @@ int npw_dtranspose(int64_t rows, int64_t cols, const double* A, int64_t lda, dou
  * matrix, zero the rest; unit_diag != 0 forces the diagonal to 1.  In place.   */
 int npw_dtri_keep(char uplo, int unit_diag, int64_t rows, int64_t cols, double* A, int64_t lda,
                   npw_stream_t stream);
+
+/* Out (n x n) <- zeros, its first nb rows <- the nb x nb diagonal blocks of the upper triangular
+ * compact-WY factor T laid side by side: LAPACK's blocked "NB-by-N" T.  Used by
+ * kernels.qr_factor_triangular, whose reference (numpywren/kernels.py:107-119) hands DTPQRT an n x n
+ * array for T with nb = min(n, 32) and returns that array as is.  No aliasing.            */
+int npw_dblockdiag_rows(int64_t n, int64_t nb, const double* T, int64_t ldt, double* Out, int64_t ldo,
+                        npw_stream_t stream);
 
 /* dst[i,j] = (dst_type) src[i,j]; types: 0 = f64, 1 = f32 */
 int npw_convert(int64_t rows, int64_t cols, const void* src, int64_t lds, int src_type, void* dst,

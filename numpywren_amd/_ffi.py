@@ -80,6 +80,7 @@ PROTOTYPES = {
     "npw_daxpby": (c_int, [_i64, _i64, c_double, _vp, _i64, c_double, _vp, _i64, _vp, _i64, _vp]),
     "npw_dtranspose": (c_int, [_i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     "npw_dtri_keep": (c_int, [c_char, c_int, _i64, _i64, _vp, _i64, _vp]),
+    "npw_dblockdiag_rows": (c_int, [_i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     "npw_convert": (c_int, [_i64, _i64, _vp, _i64, c_int, _vp, _i64, c_int, _vp]),
     "npw_fill_outer": (c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, c_double, _vp]),
     "npw_fill_random": (c_int, [_vp, _i64, _i64, _i64, c_uint64, _i64, _i64, _vp]),

@@ -75,8 +75,9 @@ def gemm(A, B):
 
 
 def qr(A):
-    """Blocked Householder QR (reference alg_wrappers.py:67-89).  The program compiles and its DAG is
-    exact; running it needs kernels.qr_factor_triangular (SURVEY.md 8f "next")."""
+    """Blocked Householder QR (reference alg_wrappers.py:67-89): same matrices, names, shapes and program.
+    Runs as the reference does, including what kernels.qr_factor_triangular and kernels.qr_leaf do as written
+    (only the first block row of Rs is a true QR factor of A; tests/golden/make_golden_qr.py pins the rest)."""
     b_fac = 2
     N = A.shape[0]
     b = A.shard_sizes[0]

@@ -157,6 +157,19 @@ __global__ void tri_keep_kernel(bool lower, bool unit, int64_t rows, int64_t col
     }
 }
 
+// Out (n x n) = 0 except its first nb rows: Out[i][c] = T[(c / nb) * nb + i][c]  -- the nb x nb diagonal blocks of
+// the compact-WY factor T side by side, which is LAPACK's blocked (nb x n) T of DGEQRT / DTPQRT.
+__global__ void blockdiag_rows_kernel(int64_t n, int64_t nb, const double* T, int64_t ldt, double* Out, int64_t ldo) {
+    NPW_FOR_2D(r, c, n, n) {
+        double v = 0.0;
+        if (r < nb) {
+            const int64_t src = (c / nb) * nb + r;
+            if (src < n) v = T[src * ldt + c];
+        }
+        Out[r * ldo + c] = v;
+    }
+}
+
 template <typename S, typename D>
 __global__ void convert_kernel(int64_t rows, int64_t cols, const S* src, int64_t lds, D* dst,
                                int64_t ldd) {
@@ -326,6 +339,16 @@ int npw_dtri_keep(char uplo, int unit_diag, int64_t rows, int64_t cols, double* 
     NPW_REQUIRE(A != nullptr && lda >= cols, "npw_dtri_keep: bad arguments");
     hipLaunchKernelGGL(tri_keep_kernel, grid2d(rows, cols), dim3(kThreads), 0, as_stream(stream),
                        uplo == 'L' || uplo == 'l', unit_diag != 0, rows, cols, A, lda);
+    NPW_LAUNCH_CHECK();
+    return NPW_OK;
+}
+
+int npw_dblockdiag_rows(int64_t n, int64_t nb, const double* T, int64_t ldt, double* Out, int64_t ldo,
+                        npw_stream_t stream) {
+    if (n <= 0) return NPW_OK;
+    NPW_REQUIRE(nb > 0 && T != nullptr && Out != nullptr && ldt >= n && ldo >= n && T != Out,
+                "npw_dblockdiag_rows: bad arguments");
+    hipLaunchKernelGGL(blockdiag_rows_kernel, grid2d(n, n), dim3(kThreads), 0, as_stream(stream), n, nb, T, ldt, Out, ldo);
     NPW_LAUNCH_CHECK();
     return NPW_OK;
 }

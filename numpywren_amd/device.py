@@ -727,6 +727,29 @@ class HipBackend(object):
         self._produced(sh, V, T, R)
         return V, T, R
 
+    def tri(self, tile, uplo, unit_diag=False, stream=None):
+        """np.triu / np.tril of a 2-D fp64 tile as a new tile; unit_diag forces ones on the diagonal."""
+        self._require_2d(tile, "tri")
+        sh = self._sh(stream)
+        out = self.copy(self.as_f64(tile, sh), sh)
+        r, c = out.shape
+        self._use(sh, out)
+        _ffi.check(self.lib.npw_dtri_keep(uplo.encode(), 1 if unit_diag else 0, r, c, out.ptr, c, sh), "tri_keep")
+        self._produced(sh, out)
+        return out
+
+    def blockdiag_rows(self, T, nb, stream=None):
+        """LAPACK's blocked nb x n form of the n x n compact-WY factor T, in the first nb rows of an n x n tile."""
+        self._require_2d(T, "blockdiag_rows")
+        sh = self._sh(stream)
+        T = self.as_f64(T, sh)
+        n = T.shape[0]
+        out = self.empty((n, n), _F64)
+        self._use(sh, T, out)
+        _ffi.check(self.lib.npw_dblockdiag_rows(n, int(nb), T.ptr, n, out.ptr, n, sh), "blockdiag_rows")
+        self._produced(sh, out)
+        return out
+
     def axpby(self, alpha, X, beta, Y, stream=None):
         """alpha * X + beta * Y for same-shape fp64 tiles (used for S0 - W style updates)."""
         sh = self._sh(stream)

@@ -363,13 +363,33 @@ def slow_qr(x):
                               "LambdaPACK program and has no HIP implementation yet")
 
 
-def fast_qr_triangular(x0, x1):
-    raise NotImplementedError("fast_qr_triangular (LAPACK dtpqrt; reference kernels.py:107-124) is the structured "
-                              "triangle-on-triangle QR of alg_wrappers.qr -- listed as 'next' in SURVEY.md 8(f)")
+@_kernel
+def _qr_factor_triangular(be, stream, x0, x1, **kwargs):
+    """QR of two stacked upper-triangular tiles (reference kernels.py:107-124: LAPACK DTPQRT with l = m,
+    nb = min(n, 32) on x0 over x1).  Returns, exactly as the reference does:
+      r  the n x n upper-triangular factor of [triu(x0); triu(x1)];
+      t  an n x n tile whose first nb rows hold DTPQRT's blocked T (the nb x nb diagonal blocks of the compact-WY
+         factor side by side), zero elsewhere -- the caller (qr_trailing_update) then uses it as if it were the full T;
+      v  `tril` of what DTPQRT leaves in x1 with a unit diagonal.  DTPQRT stores its reflectors in the *upper* triangle
+         of x1 and does not touch the part below, so this is tril(x1, -1) + I: the identity for the triangular inputs of
+         the QR tree.  (The reference's alg_wrappers.qr therefore only gets the first block row of R right; we reproduce
+         it as written -- see tests/golden/make_golden_qr.py and DESIGN.md section 7.)
+    Dense formulation: the Householder vectors of the stacked matrix keep DTPQRT's sparsity, so one npw_dgeqrt of the
+    2n x n stack gives the same R and the same per-panel T blocks to rounding."""
+    n = x0.shape[-1]
+    if tuple(x0.shape) != (n, n) or tuple(x1.shape) != (n, n):
+        raise NotImplementedError(f"qr_factor_triangular of {x0.shape} over {x1.shape}: only square tiles of equal size "
+                                  "(all the QR tree produces) are supported")
+    stacked = be.vstack([be.tri(x0, "U", False, stream), be.tri(x1, "U", False, stream)], stream)
+    _, T, R = be.geqrt(stacked, stream)
+    v = be.tri(x1, "L", True, stream)
+    t = be.blockdiag_rows(T, min(n, 32), stream)
+    return v, t, R
 
 
-def qr_factor_triangular(x0, x1, **kwargs):
-    return fast_qr_triangular(x0, x1)
+qr_factor_triangular = _qr_factor_triangular
+fast_qr_triangular = _qr_factor_triangular
+qr_factor_triangular._npw_latency_bound = True
 
 
 def banded_to_bidiagonal(x):

@@ -146,5 +146,21 @@ class OracleBackend(object):
         v, t, r = oracle.fast_qr(A.array)
         return HostTile(v), HostTile(t), HostTile(r)
 
+    def tri(self, tile, uplo, unit_diag=False, stream=None):
+        a = np.triu(tile.array) if uplo.upper() == "U" else np.tril(tile.array)
+        a = np.array(a, dtype=np.float64)
+        if unit_diag:
+            a[np.diag_indices(min(a.shape))] = 1.0
+        return HostTile(a)
+
+    def blockdiag_rows(self, T, nb, stream=None):
+        t = T.array
+        n = t.shape[0]
+        out = np.zeros((n, n))
+        for c0 in range(0, n, nb):
+            c1 = min(n, c0 + nb)
+            out[:c1 - c0, c0:c1] = t[c0:c1, c0:c1]
+        return HostTile(out)
+
     def axpby(self, alpha, X, beta, Y, stream=None):
         return HostTile(alpha * X.array + beta * Y.array)

@@ -276,3 +276,27 @@ def test_bigmatrix_hbm_roundtrips(hbm_store):
     assert np.array_equal(get_backend().to_host(lam.get_tile(0, 1)), X[:32, 32:64])
     m.free()
     assert m.block_idxs_exist == []
+
+
+QRG = np.load(os.path.join(GOLDEN, "qr.npz"))
+
+
+@pytest.mark.parametrize("tag,b", [("28_7", 7), ("16_8", 8), ("24_8", 8), ("80_40", 40)])
+def test_qr_golden(tag, b, hbm_store):
+    """alg_wrappers.qr on the GPU against the R tiles of the reference's own run (as written: only the first
+    block row is a true QR factor, see kernels.qr_factor_triangular)."""
+    Xh = QRG[f"qr_{tag}/X"]
+    X = BigMatrix(f"QR_input_{tag}", shape=Xh.shape, shard_sizes=(b, b))
+    shard_matrix(X, Xh)
+    program, meta = alg_wrappers.qr(X)
+    res = run(program, pipeline_width=1)
+    assert program.program_status() == lp.PS.SUCCESS, program.exceptions
+    assert len(res["executed_messages"]) == int(QRG[f"qr_{tag}/meta"][4])
+    Rs = meta["outputs"][0]
+    nb = Xh.shape[0] // b
+    for i in range(nb):
+        for k in range(i, nb):
+            np.testing.assert_allclose(Rs.get_block(i, k, 0), QRG[f"qr_{tag}/R_{i}_{k}"], rtol=1e-8, atol=1e-8,
+                                       err_msg=f"R[{i},{k}]")
+    R = np.linalg.qr(Xh)[1]
+    np.testing.assert_allclose(np.abs(Rs.get_block(0, 0, 0)), np.abs(R[:b, :b]), atol=1e-10)

@@ -164,3 +164,24 @@ def test_duplicate_and_replayed_tasks_do_not_double_count(oracle_backend):
     job_runner.lambdapack_run(program, timeout=60)
     assert program.program_status() == lp.PS.SUCCESS
     np.testing.assert_allclose(meta["outputs"][0].numpy(), ALG["cholesky_32_8/L"], rtol=1e-12, atol=1e-12)
+
+
+QRG = np.load(os.path.join(GOLDEN, "qr.npz"))
+
+
+@pytest.mark.parametrize("tag,b", [("28_7", 7), ("16_8", 8), ("24_8", 8), ("80_40", 40)])
+def test_qr(tag, b, oracle_backend):
+    """alg_wrappers.qr (reference alg_wrappers.py:67-89) end to end; R tiles against the reference's own run."""
+    Xh = QRG[f"qr_{tag}/X"]
+    X = BigMatrix(f"QR_input_{tag}", shape=Xh.shape, shard_sizes=(b, b))
+    shard_matrix(X, Xh)
+    program, meta = alg_wrappers.qr(X)
+    res = run(program, pipeline_width=1)
+    assert program.program_status() == lp.PS.SUCCESS
+    assert len(res["executed_messages"]) == int(QRG[f"qr_{tag}/meta"][4])
+    Rs = meta["outputs"][0]
+    nb = Xh.shape[0] // b
+    for i in range(nb):
+        for k in range(i, nb):
+            np.testing.assert_allclose(Rs.get_block(i, k, 0), QRG[f"qr_{tag}/R_{i}_{k}"], rtol=1e-9, atol=1e-9,
+                                       err_msg=f"R[{i},{k}]")

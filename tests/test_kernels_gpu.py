@@ -235,3 +235,27 @@ def test_tile_size_properties():
     YtY = be.gemm(Y, Y, True, False)
     D = be.gemm(R, R, True, False, alpha=1.0, beta=-1.0, C=YtY)
     assert np.sqrt(be.sumsq(D) / be.sumsq(YtY)) < 1e-13
+
+
+QRG = np.load(os.path.join(GOLDEN, "qr.npz"))
+
+
+@pytest.mark.parametrize("tag", ["tri_4", "tri_7", "tri_8", "tri_32", "tri_40", "tri_64", "tri_full_8", "tri_full_40"])
+def test_qr_factor_triangular_golden(tag):
+    v, t, r = kernels.qr_factor_triangular(QRG[f"{tag}/x0"], QRG[f"{tag}/x1"])
+    np.testing.assert_allclose(v, QRG[f"{tag}/v"], atol=1e-13)
+    np.testing.assert_allclose(t, QRG[f"{tag}/t"], atol=1e-11)
+    np.testing.assert_allclose(r, QRG[f"{tag}/r"], atol=1e-11)
+
+
+def test_qr_factor_triangular_tile_size():
+    """300 x 300 triangles: R^T R == x0^T x0 + x1^T x1 and the blocked T has 32 non-zero rows."""
+    rng = np.random.default_rng(31)
+    x0, x1 = np.triu(rng.standard_normal((300, 300))), np.triu(rng.standard_normal((300, 300)))
+    v, t, r = kernels.qr_factor_triangular(x0, x1)
+    G = x0.T @ x0 + x1.T @ x1
+    np.testing.assert_allclose(r.T @ r, G, atol=1e-10 * np.abs(G).max())
+    assert not np.tril(r, -1).any() and not t[32:].any() and np.array_equal(v, np.eye(300))
+    vo, to, ro = oracle.qr_factor_triangular(x0, x1)
+    np.testing.assert_allclose(t, to, atol=1e-10)
+    np.testing.assert_allclose(r, ro, atol=1e-10)

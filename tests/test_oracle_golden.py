@@ -158,3 +158,34 @@ def test_block_indexing():
             assert [list(x) for x in oracle.block_idx_to_real_idx(shape, shards, k["bidx"])] == k["real"]
             key_base = k["key"].rsplit("/", 1)[0]
             assert oracle.shard_key(key_base, shape, shards, k["bidx"]) == k["key"]
+
+
+# ---- blocked QR path: qr_factor_triangular and the QR program -------------------------------
+QRG = np.load(os.path.join(os.path.dirname(__file__), "golden", "qr.npz"))
+
+
+@pytest.mark.parametrize("tag", ["tri_4", "tri_7", "tri_8", "tri_32", "tri_40", "tri_64", "tri_full_8", "tri_full_40"])
+def test_qr_factor_triangular_golden(tag):
+    v, t, r = oracle.qr_factor_triangular(QRG[f"{tag}/x0"], QRG[f"{tag}/x1"])
+    np.testing.assert_allclose(v, QRG[f"{tag}/v"], atol=1e-13)
+    np.testing.assert_allclose(t, QRG[f"{tag}/t"], atol=1e-12)
+    np.testing.assert_allclose(r, QRG[f"{tag}/r"], atol=1e-12)
+    n = r.shape[0]
+    assert not t[min(n, 32):].any()                      # DTPQRT's blocked T only fills nb rows
+    # the triangle-on-triangle factor is the R of the dense stacked matrix
+    R = np.linalg.qr(np.vstack([np.triu(QRG[f"{tag}/x0"]), np.triu(QRG[f"{tag}/x1"])]))[1]
+    np.testing.assert_allclose(np.abs(r), np.abs(R), atol=1e-11)
+
+
+@pytest.mark.parametrize("tag,b", [("28_7", 7), ("16_8", 8), ("24_8", 8), ("80_40", 40)])
+def test_qr_program_golden(tag, b):
+    X = QRG[f"qr_{tag}/X"]
+    Rs = oracle.qr(X, b)
+    nb = X.shape[0] // b
+    for i in range(nb):
+        for k in range(i, nb):
+            np.testing.assert_allclose(Rs.get((i, k, 0)), QRG[f"qr_{tag}/R_{i}_{k}"], rtol=1e-9, atol=1e-9,
+                                       err_msg=f"R[{i},{k}]")
+    # what the reference's algorithm does get right: the first diagonal block (up to row signs)
+    R = np.linalg.qr(X)[1]
+    np.testing.assert_allclose(np.abs(Rs.get((0, 0, 0))), np.abs(R[:b, :b]), atol=1e-10)
