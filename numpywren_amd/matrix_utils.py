@@ -90,7 +90,7 @@ def get_local_matrix(bigm, workers=1, mmap_loc=None, big_axis=0):
     for bidx in itertools.product(*per_axis):
         real = BigMatrixRealIdx(bigm, bidx)
         sl = tuple(slice(s, e) for s, e in real)
-        out[sl] = bigm.get_block(*bidx)
+        out[sl] = np.asarray(bigm.get_block(*bidx)).reshape(out[sl].shape)  # autosqueeze drops singleton shard axes
     return out
 
 
