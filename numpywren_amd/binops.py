@@ -1,21 +1,43 @@
-"""Binary-operator surface of the reference (numpywren/binops.py).  `gemm` there is a
-non-LambdaPACK blocked matmul fanned out with pywren.map and used by the experiments to form
-X.X^T (binops.py:107-174); here it runs the LambdaPACK GEMM program on the local GPU.  The
-remaining names are stubs in the reference too."""
-from . import alg_wrappers, job_runner
-from . import lambdapack as lp
+"""Binary-operator surface of the reference (numpywren/binops.py).
+
+`gemm` there is a non-LambdaPACK blocked matmul fanned out with pywren.map -- every experiment uses it to form
+X.X^T before the factorisation (binops.py:107-174 with the per-block worker _gemm_remote_0, 20-34).  Here the
+same output matrix (key `gemm(BigMatrix(x), BigMatrix(y))`, shape, shard sizes, dtype, header) is produced by the
+GPU the caller runs on: one accumulating MFMA GEMM per (output block, reduction index), tiles resident in HBM.
+`pwex`, `tasks_per_job`, `local`, `gemm_impl`, `gemm_chunk_size` are accepted and ignored (they steer the pywren
+fan-out).  The remaining names are stubs in the reference too."""
+import numpy as np
+
+from . import matrix_utils
+from .device import get_backend
+from .matrix import BigMatrix
 
 
-def gemm(pwex, X, Y, out_bucket=None, tasks_per_job=1, local=False, dtype=None, overwrite=True, gemm_impl=0,
+def gemm(pwex, X, Y, out_bucket=None, tasks_per_job=1, local=False, dtype=np.float64, overwrite=True, gemm_impl=0,
          gemm_chunk_size=16):
-    program, meta = alg_wrappers.gemm(X, Y)
-    program.start()
-    job_runner.lambdapack_run(program)
-    program.wait()
-    if program.program_status() != lp.PS.SUCCESS:
-        raise Exception("gemm failed: {0}".format(program.exceptions))
-    program.free()
-    return meta["outputs"][0]
+    """XY = X . Y over BigMatrices (or views such as X.T).  Reference binops.py:107-174."""
+    reduce_idxs = Y._block_idxs(axis=0)
+    if out_bucket is None:
+        out_bucket = X.bucket
+    root_key = matrix_utils.generate_key_name_binop(X, Y, "gemm")
+    if Y.shard_sizes[0] != X.shard_sizes[1]:
+        raise Exception("X dim 1 shard size must match Y dim 0 shard size")
+    XY = BigMatrix(root_key, shape=(X.shape[0], Y.shape[1]), bucket=out_bucket,
+                   shard_sizes=[X.shard_sizes[0], Y.shard_sizes[1]], dtype=dtype, write_header=True)
+    todo = list(XY.block_idxs) if overwrite else list(XY.block_idxs_not_exist)
+    be = get_backend()
+    f32 = np.dtype(dtype) == np.float32
+    for i, j in todo:
+        acc = None
+        for r in reduce_idxs:
+            a, b = X.get_tile(i, r), Y.get_tile(r, j)
+            if f32:
+                a, b = be.convert(a, np.float32), be.convert(b, np.float32)
+            else:
+                a, b = be.as_f64(a), be.as_f64(b)
+            acc = be.gemm(a, b, False, False, alpha=1.0, beta=0.0 if acc is None else 1.0, C=acc, out=acc)
+        XY.put_tile(acc, i, j)
+    return XY
 
 
 def _stub(name):
