@@ -172,7 +172,9 @@ def init_process_group(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     gpu = torch.cuda.is_available()
     if backend is None:
-        backend = "cpu:gloo,cuda:nccl" if gpu else "gloo"
+        # NUMPYWREN_AMD_DIST_BACKEND=gloo stages payloads through the host: lets several ranks share one GPU
+        # (RCCL refuses two ranks on one device), which is how the GPU-side logic is tested on a 1-GPU box
+        backend = os.environ.get("NUMPYWREN_AMD_DIST_BACKEND") or ("cpu:gloo,cuda:nccl" if gpu else "gloo")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")
     if "nccl" in backend:
