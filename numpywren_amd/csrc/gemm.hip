@@ -41,7 +41,7 @@ struct MfmaTraits<double> {
     using acc_t = d4_t;
     using vec_t = d2_t;  // 16-byte chunk
     static constexpr int VEC = 2;
-    static constexpr int PADK = 2;  // KC row padding (elements)
+    static constexpr int PADK = 0;  // KC rows are not padded: 16-byte chunks are XOR-swizzled instead (kc_off)
     __device__ static inline acc_t mfma(double a, double b, acc_t c) {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
     }
@@ -61,17 +61,29 @@ struct MfmaTraits<float> {
     __device__ static inline int acc_row(int g, int r) { return 4 * g + r; }
 };
 
-// k index inside a BK tile consumed by lane group g at MFMA step s.  Any bijection works
-// as long as A and B agree; fp32 pairs (2g, 2g+1) so a KC fragment is one ds_read_b64.
+// k index inside a BK tile consumed by lane group g at MFMA step s.  Any bijection works as long as A and B
+// agree: steps (2p, 2p+1) of lane group g use the adjacent pair k = 8p + 2g, 8p + 2g + 1, so a KC fragment for
+// two steps is ONE load (ds_read_b128 for fp64, ds_read_b64 for fp32).
 template <typename T>
-__device__ inline int k_of(int s, int g);
-template <>
-__device__ inline int k_of<double>(int s, int g) {
-    return 4 * s + g;
-}
-template <>
-__device__ inline int k_of<float>(int s, int g) {
+__device__ inline int k_of(int s, int g) {
     return 8 * (s >> 1) + 2 * g + (s & 1);
+}
+
+// Element offset of (row, k) inside a KC tile (`Xs[row][k]`).  fp32: padded rows.  fp64: rows of exactly BK
+// elements whose 16-byte chunks are XOR-swizzled with the row number.  The padded fp64 layout (ld = BK + 2) was
+// conflict-free for ds_read_b64, but hipcc fuses the two fragment loads of consecutive steps into ds_read2_b64,
+// which is serviced in 16-lane groups over 32 banks at half the rate: PMC showed 39 % of the LDS cycles of the
+// trailing update as bank conflicts.  With the k pairing above a fragment pair is one ds_read_b128 (16-lane groups
+// {0-3,12-15,20-27},...: rows li and lane groups g, g+1 mixed), and chunk ^ f(row) makes each group cover all 64
+// banks exactly once; the 8-lane groups of ds_write_b128 stay inside one row and are conflict-free as well.
+template <typename T, int BK>
+__device__ inline int kc_off(int row, int k) {
+    if constexpr (sizeof(T) == 8 && (BK == 16 || BK == 32)) {
+        const int f = (BK == 16) ? ((row >> 1) & 7) : (row & 15);
+        return row * BK + ((((k >> 1) ^ f) << 1) | (k & 1));
+    } else {
+        return row * (BK + MfmaTraits<T>::PADK) + k;
+    }
 }
 
 template <typename T>
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
             const int id = tid + 256 * c;
             if constexpr (A_KC) {
                 const int row = id / (BK / VEC), kc = (id % (BK / VEC)) * VEC;
-                *reinterpret_cast<vec_t*>(&smem[buf * STAGE + row * LDKC + kc]) = ra[c];
+                *reinterpret_cast<vec_t*>(&smem[buf * STAGE + kc_off<T, BK>(row, kc)]) = ra[c];
             } else {
                 const int kk = id / (BM / VEC), mc = (id % (BM / VEC)) * VEC;
                 *reinterpret_cast<vec_t*>(&smem[buf * STAGE + kk * LDA_MC + mc]) = ra[c];
@@ -286,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
             const int id = tid + 256 * c;
             if constexpr (B_KC) {
                 const int row = id / (BK / VEC), kc = (id % (BK / VEC)) * VEC;
-                *reinterpret_cast<vec_t*>(&smem[buf * STAGE + A_ELEMS + row * LDKC + kc]) = rb[c];
+                *reinterpret_cast<vec_t*>(&smem[buf * STAGE + A_ELEMS + kc_off<T, BK>(row, kc)]) = rb[c];
             } else {
                 const int kk = id / (BN / VEC), nc = (id % (BN / VEC)) * VEC;
                 *reinterpret_cast<vec_t*>(&smem[buf * STAGE + A_ELEMS + kk * LDB_MC + nc]) = rb[c];
@@ -298,28 +310,61 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
     auto compute = [&](int buf) {
         const T* a_s = smem + buf * STAGE;
         const T* b_s = smem + buf * STAGE + A_ELEMS;
+        if constexpr (sizeof(T) == 8) {
+            // two MFMA steps per fragment load: k = kk, kk + 1 are adjacent (one 16-byte LDS read for KC operands)
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            const int kk = k_of<T>(s, lg);
-            T af[TM], bf[TN];
+            for (int s = 0; s < KSTEPS; s += 2) {
+                const int kk = k_of<T>(s, lg);
+                vec_t af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if constexpr (A_KC)
-                    af[i] = a_s[(wm0 + 16 * i + li) * LDKC + kk];
-                else
-                    af[i] = a_s[kk * LDA_MC + wm0 + 16 * i + li];
+                for (int i = 0; i < TM; ++i) {
+                    if constexpr (A_KC) {
+                        af[i] = *reinterpret_cast<const vec_t*>(&a_s[kc_off<T, BK>(wm0 + 16 * i + li, kk)]);
+                    } else {
+                        af[i][0] = a_s[kk * LDA_MC + wm0 + 16 * i + li];
+                        af[i][1] = a_s[(kk + 1) * LDA_MC + wm0 + 16 * i + li];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (B_KC) {
+                        bf[j] = *reinterpret_cast<const vec_t*>(&b_s[kc_off<T, BK>(wn0 + 16 * j + li, kk)]);
+                    } else {
+                        bf[j][0] = b_s[kk * LDB_MC + wn0 + 16 * j + li];
+                        bf[j][1] = b_s[(kk + 1) * LDB_MC + wn0 + 16 * j + li];
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = TR::mfma(af[i][h], bf[j][h], acc[i][j]);
             }
+        } else {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if constexpr (B_KC)
-                    bf[j] = b_s[(wn0 + 16 * j + li) * LDKC + kk];
-                else
-                    bf[j] = b_s[kk * LDB_MC + wn0 + 16 * j + li];
+            for (int s = 0; s < KSTEPS; ++s) {
+                const int kk = k_of<T>(s, lg);
+                T af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    if constexpr (A_KC)
+                        af[i] = a_s[kc_off<T, BK>(wm0 + 16 * i + li, kk)];
+                    else
+                        af[i] = a_s[kk * LDA_MC + wm0 + 16 * i + li];
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (B_KC)
+                        bf[j] = b_s[kc_off<T, BK>(wn0 + 16 * j + li, kk)];
+                    else
+                        bf[j] = b_s[kk * LDB_MC + wn0 + 16 * j + li];
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = TR::mfma(af[i], bf[j], acc[i][j]);
             }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = TR::mfma(af[i], bf[j], acc[i][j]);
         }
     };
 
