@@ -360,7 +360,8 @@ int main(int argc, char** argv) {
         if (n >= 4096) {   // latency table for the small products potrf/trsm recursion issues
             const int shapes[][3] = {{128, 128, 128}, {256, 256, 128}, {256, 256, 256}, {512, 512, 512}, {1024, 1024, 1024},
                                      {2048, 128, 128}, {4096, 128, 128}, {4096, 256, 256}, {4096, 512, 512},
-                                     {4096, 1024, 1024}, {2048, 2048, 2048}, {4096, 2048, 2048}};
+                                     {4096, 1024, 1024}, {2048, 2048, 2048}, {4096, 2048, 2048},
+                                     {3968, 3968, 128}, {3968, 3968, 256}, {3968, 3968, 512}, {2048, 2048, 128}, {1024, 1024, 128}};
             for (auto& sh : shapes) {
                 int m = sh[0], nn = sh[1], k = sh[2];
                 for (int v = 0; v < 2; ++v) {
