@@ -15,10 +15,11 @@
 //     (launch_bounds(256, 2)) cover each other's barrier stalls.
 //   * each operand keeps its *natural* layout in LDS, so no transposition is needed
 //     while staging:
-//       "KC" (k contiguous in memory: A of op N, B of op T):  Xs[row][k], ld = BK + PADK
+//       "KC" (k contiguous in memory: A of op N, B of op T):  Xs[row][k]; fp64: unpadded rows with
+//            XOR-swizzled 16-byte chunks (kc_off), fp32: ld = BK + 4
 //       "MC" (m/n contiguous in memory: A of op T, B of op N): Xs[k][col], ld = BMN + 16
-//     both paddings make the fragment ds_reads bank-conflict free (checked against the
-//     64-bank ds_read_b64 / 32-bank ds_read_b32 rules).
+//     MFMA step pairs (2p, 2p+1) use adjacent k (k_of), so a KC fragment for two steps is one
+//     ds_read_b128 (fp64) / ds_read_b64 (fp32); SQ_LDS_BANK_CONFLICT = 0 for the trailing update.
 //   * 1-D grid with an XCD-aware, grouped block->tile map so the 8 private L2s each see a
 //     compact patch of the output.
 //   * EDGE instantiations (any shape / alignment) guard every global access; the fast
