@@ -15,6 +15,9 @@
 //   T off-diagonal blocks bottom-up:  T12 = -T1 * (V1^T V2) * T2 with V^T V from one big GEMM.
 #include "npw_internal.h"
 
+#include <atomic>
+#include <chrono>
+
 namespace npw {
 namespace {
 
@@ -304,6 +307,226 @@ __global__ __launch_bounds__(SLAB) void qr_panel2_finish(int mp, int pb, const d
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Panel kernel v3: ONE launch per tall panel (mp > 1024).  Same arithmetic as the per-column launches above,
+// but the workgroups stay resident for all pb columns: every thread keeps its row of the panel (32 values) in
+// registers, the per-column hand-off between the slabs (one partial-sum vector per slab + the next pivot row)
+// goes through device-coherent memory, and the columns are separated by a grid barrier on a monotonic counter
+// instead of a kernel boundary (~20 us per column -> a few).
+//   publish : write-through stores (sc1), then s_waitcnt vmcnt(0) in every publishing wave, workgroup barrier,
+//             one relaxed agent-scope atomic add by thread 0  (no release fence: see factor.hip)
+//   consume : thread 0 spins on the counter (relaxed, s_sleep), workgroup barrier, sc1 loads of the partials
+// The grid (<= 32 workgroups of 256 threads, no LDS to speak of) is always co-resident.
+// ------------------------------------------------------------------------------------------------
+// A hand-off slot: value + sequence tag, written with ONE 16-byte write-through store and read with one 16-byte
+// device-coherent load, so a reader that sees the expected tag also sees the value: arrival of the data is the
+// synchronisation (no counter, no fence, no separate barrier; one memory hop per column instead of three).
+typedef double slot_t __attribute__((ext_vector_type(2)));  // {value, tag bits}
+
+__device__ inline void st_slot(slot_t* p, double v, unsigned long long tag) {
+    slot_t x;
+    x[0] = v;
+    x[1] = __longlong_as_double((long long)tag);
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+}
+// poll up to four slots until each carries `tag` (slots whose `need` flag is false are not waited for)
+__device__ inline void ld_slots4(const slot_t* p0, const slot_t* p1, const slot_t* p2, const slot_t* p3, bool n0, bool n1,
+                                 bool n2, bool n3, unsigned long long tag, double& a, double& b, double& c, double& d) {
+    const double want = __longlong_as_double((long long)tag);
+    for (int spin = 0; spin < (1 << 22); ++spin) {  // bounded: a lost hand-off must not hang the GPU
+        slot_t x0, x1, x2, x3;
+        asm volatile(
+            "global_load_dwordx4 %0, %4, off sc1\n\t"
+            "global_load_dwordx4 %1, %5, off sc1\n\t"
+            "global_load_dwordx4 %2, %6, off sc1\n\t"
+            "global_load_dwordx4 %3, %7, off sc1\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
+            : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+            : "memory");
+        a = x0[0];
+        b = x1[0];
+        c = x2[0];
+        d = x3[0];
+        const bool ok = (!n0 || __double_as_longlong(x0[1]) == __double_as_longlong(want)) &&
+                        (!n1 || __double_as_longlong(x1[1]) == __double_as_longlong(want)) &&
+                        (!n2 || __double_as_longlong(x2[1]) == __double_as_longlong(want)) &&
+                        (!n3 || __double_as_longlong(x3[1]) == __double_as_longlong(want));
+        if (ok) return;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+__global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double* W, int64_t ldw, double* Tjj, int64_t ldt,
+                                                         double* Rjj, int64_t ldr, slot_t* part /* [2][G][PB] */,
+                                                         slot_t* rowbuf /* [2][PB] */, unsigned long long tag0) {
+    constexpr int CLD = SLAB + 8;
+    __shared__ double q[PB], d[PB], hh[3], Tl[PB * PB];
+    __shared__ double cols[PB * CLD];
+    const int tid = threadIdx.x;
+    const int G = gridDim.x;
+    const int r = blockIdx.x * SLAB + tid;
+    const bool live = r < mp;
+    double pk[PB], acc[PB];
+#pragma unroll
+    for (int k = 0; k < PB; ++k) pk[k] = (live && k < pb) ? W[(int64_t)r * ldw + k] : 0.0;
+    if (blockIdx.x == 0)
+        for (int i = tid; i < PB * PB; i += SLAB) Tl[i] = 0.0;
+
+    // partial sums of (column c)^T (every column) over this slab's rows below the pivot, published for step c
+    auto publish = [&](int c) {
+        slot_t* mine = part + ((size_t)(c & 1) * G + blockIdx.x) * PB;
+        // column sums over the slab's 256 rows through LDS: thread t drops its 32 products at cols[k][t], then
+        // 8 lanes per column add 32 of them each (stride chosen so that both passes are bank-conflict free)
+#pragma unroll
+        for (int k = 0; k < PB; ++k) cols[k * CLD + tid] = acc[k];
+        __syncthreads();
+        {
+            const int k = tid >> 3, sub = tid & 7;
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < SLAB / 8; ++i) t += cols[k * CLD + i * 8 + sub];
+            t += __shfl_down(t, 4, 8);
+            t += __shfl_down(t, 2, 8);
+            t += __shfl_down(t, 1, 8);
+            if (sub == 0 && k < pb) st_slot(mine + k, t, tag0 + (unsigned)c);
+        }
+    };
+
+    {
+        const double x = (live && r > 0) ? pk[0] : 0.0;
+#pragma unroll
+        for (int k = 0; k < PB; ++k) acc[k] = x * pk[k];
+        if (r == 0) {
+#pragma unroll
+            for (int k = 0; k < PB; ++k) st_slot(rowbuf + k, pk[k], tag0);
+        }
+        publish(0);
+    }
+
+    for (int c = 0; c < pb; ++c) {
+        const slot_t* pin = part + (size_t)(c & 1) * G * PB;
+        const slot_t* rin = rowbuf + (size_t)(c & 1) * PB;
+        const unsigned long long tag = tag0 + (unsigned)c;
+        {
+            // 8 lanes per column gather the slab partials (fixed order: deterministic), then fold
+            const int k = tid >> 3, sub = tid & 7;
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+            if (tid >= SLAB - PB) {  // the last wave's top lanes fetch the pivot row (overwritten below with d_k)
+                const int kk = tid - (SLAB - PB);
+                if (kk < pb) {
+                    double u0, u1, u2, u3;
+                    ld_slots4(rin + kk, rin + kk, rin + kk, rin + kk, true, false, false, false, tag, u0, u1, u2, u3);
+                    d[kk] = u0;
+                }
+            }
+            if (k < pb) {
+                for (int gb = 0; gb < G; gb += 32) {  // 32 slabs (8192 rows) per round
+                    const int g0 = gb + sub, g1 = g0 + 8, g2 = g0 + 16, g3 = g0 + 24;
+                    const slot_t* base = pin + k;
+                    double u0, u1, u2, u3;
+                    ld_slots4(base + (size_t)(g0 < G ? g0 : 0) * PB, base + (size_t)(g1 < G ? g1 : 0) * PB,
+                              base + (size_t)(g2 < G ? g2 : 0) * PB, base + (size_t)(g3 < G ? g3 : 0) * PB, g0 < G, g1 < G,
+                              g2 < G, g3 < G, tag, u0, u1, u2, u3);
+                    t0 += (g0 < G) ? u0 : 0.0;
+                    t1 += (g1 < G) ? u1 : 0.0;
+                    t2 += (g2 < G) ? u2 : 0.0;
+                    t3 += (g3 < G) ? u3 : 0.0;
+                }
+            }
+            double t = ((t0 + t1) + t2) + t3;
+            t += __shfl_down(t, 4, 8);
+            t += __shfl_down(t, 2, 8);
+            t += __shfl_down(t, 1, 8);
+            if (sub == 0 && k < pb) q[k] = t;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const double alpha = d[c], ss = q[c];
+            double tau = 0.0, scale = 0.0, beta = alpha;
+            if (ss != 0.0) {
+                const double nrm = sqrt(fma(alpha, alpha, ss));
+                beta = (alpha >= 0.0) ? -nrm : nrm;
+                tau = (beta - alpha) / beta;
+                scale = 1.0 / (alpha - beta);
+            }
+            hh[0] = tau;
+            hh[1] = scale;
+            hh[2] = beta;
+        }
+        __syncthreads();
+        const double tau = hh[0], scale = hh[1], beta = hh[2];
+        if (tid < pb) d[tid] = d[tid] + scale * q[tid];
+        __syncthreads();
+
+#pragma unroll
+        for (int k = 0; k < PB; ++k) acc[k] = 0.0;
+        if (live && r >= c) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < PB; ++k)
+                if (k == c) v = (r == c) ? 1.0 : pk[k] * scale;
+#pragma unroll
+            for (int k = 0; k < PB; ++k) {
+                if (k < pb) {
+                    if (k > c)
+                        pk[k] = fma(-tau * d[k], v, pk[k]);
+                    else if (k == c)
+                        pk[k] = v;
+                }
+            }
+            if (c + 1 < pb) {
+                if (r == c + 1) {
+                    slot_t* rout = rowbuf + (size_t)((c + 1) & 1) * PB;
+#pragma unroll
+                    for (int k = 0; k < PB; ++k) st_slot(rout + k, pk[k], tag + 1);
+                }
+                double xn = 0.0;
+#pragma unroll
+                for (int k = 0; k < PB; ++k)
+                    if (k == c + 1) xn = pk[k];
+                if (r <= c + 1) xn = 0.0;
+#pragma unroll
+                for (int k = 0; k < PB; ++k) acc[k] = xn * pk[k];
+            }
+            if (r == c) {  // the diagonal entry of R replaces the implicit 1 of v once the sums are formed
+#pragma unroll
+                for (int k = 0; k < PB; ++k)
+                    if (k == c) pk[k] = beta;
+            }
+        }
+        if (blockIdx.x == 0) {
+            // DLARFT: T[0:c, c] = -tau * T[0:c, 0:c] * z,  z_k = d_k (k < c);  T[c][c] = tau
+            if (tid < c) {
+                double sacc = 0.0;
+                for (int j = tid; j < c; ++j) sacc = fma(Tl[tid * PB + j], d[j], sacc);
+                Tl[tid * PB + c] = -tau * sacc;
+            } else if (tid == c) {
+                Tl[c * PB + c] = tau;
+            }
+        }
+        if (c + 1 < pb) publish(c + 1);
+    }
+
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < PB; ++k) {
+            if (k < pb) {
+                W[(int64_t)r * ldw + k] = (r > k) ? pk[k] : (r == k ? 1.0 : 0.0);
+                if (r < pb) Rjj[(int64_t)r * ldr + k] = (r <= k) ? pk[k] : 0.0;
+            }
+        }
+    }
+    if (blockIdx.x == 0) {
+        __syncthreads();
+        for (int i = tid; i < pb * pb; i += SLAB) {
+            const int a = i / pb, b = i - a * pb;
+            Tjj[(int64_t)a * ldt + b] = Tl[a * PB + b];
+        }
+    }
+}
+
 struct QrWorkspace {
     double* Pt;   // PB x m
     double* X1;   // PB x n
@@ -313,6 +536,7 @@ struct QrWorkspace {
     double* Part;    // 2 x slabs x PB   partial sums of the multi-workgroup panel
     double* RowBuf;  // 2 x PB
     double* Tg;      // PB x PB
+    unsigned* Counters;  // one grid-barrier counter per panel (panel kernel v3)
 };
 
 inline size_t align2(size_t x) { return (x + 1) & ~(size_t)1; }
@@ -331,10 +555,12 @@ QrWorkspace carve(void* ws, int64_t m, int64_t n) {
     q.Tmp = p;
     p += align2((size_t)((n + 1) / 2 + PB) * n);
     q.Part = p;
-    p += align2((size_t)2 * ceil_div(m, SLAB) * PB);
+    p += align2((size_t)4 * ceil_div(m, SLAB) * PB);
     q.RowBuf = p;
-    p += 2 * PB;
+    p += 4 * PB;
     q.Tg = p;
+    p += PB * PB;
+    q.Counters = reinterpret_cast<unsigned*>(p);
     return q;
 }
 
@@ -369,8 +595,8 @@ extern "C" {
 size_t npw_dgeqrt_workspace_bytes(int64_t m, int64_t n) {
     if (m <= 0 || n <= 0) return 0;
     const size_t doubles = align2((size_t)PB * m) + 2 * align2((size_t)PB * n) + align2((size_t)n * n) +
-                           align2((size_t)((n + 1) / 2 + PB) * n) + align2((size_t)2 * ceil_div(m, SLAB) * PB) +
-                           2 * PB + PB * PB;
+                           align2((size_t)((n + 1) / 2 + PB) * n) + align2((size_t)4 * ceil_div(m, SLAB) * PB) +
+                           4 * PB + PB * PB + align2((size_t)ceil_div(n, PB) / 2 + 2);
     return doubles * sizeof(double);
 }
 
@@ -393,13 +619,28 @@ int npw_dgeqrt(int64_t m, int64_t n, const double* A, int64_t lda, double* V, in
     NPW_HIP_CHECK(hipMemset2DAsync(T, ldt * 8, 0, n * 8, n, s));
     NPW_HIP_CHECK(hipMemset2DAsync(R, ldr * 8, 0, n * 8, n, s));
 
+    static const bool panel_v2 = [] {
+        const char* e = getenv("NPW_QR_PANEL");
+        return e && e[0] == '2';  // one launch per column (kept for comparison)
+    }();
+    // sequence tags of the panel kernel's hand-off slots: unique per call (process-wide counter seeded from the
+    // clock), panel and column, so that stale slots in a recycled workspace can never look current
+    static std::atomic<unsigned long long> call_counter{
+        (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() & 0x3fffffffULL};
+    const unsigned long long call_tag = (call_counter.fetch_add(1) + 1) << 24;
     for (int64_t j0 = 0; j0 < n; j0 += PB) {
         const int64_t pb = (n - j0 < PB) ? n - j0 : PB;
         const int64_t mp = m - j0;
         double* Wp = V + j0 * ldv + j0;
-        if (mp <= 1024) {
+        if (panel_v2 && mp <= 1024) {
             hipLaunchKernelGGL(qr_panel_kernel, dim3(1), dim3(PANEL_THREADS), 0, s, (int)mp, (int)pb, Wp, ldv, q.Pt,
                                mp, T + j0 * ldt + j0, ldt, R + j0 * ldr + j0, ldr);
+            NPW_LAUNCH_CHECK();
+        } else if (!panel_v2) {
+            const int G = (int)ceil_div(mp, SLAB);
+            hipLaunchKernelGGL(qr_panel3_kernel, dim3(G), dim3(SLAB), 0, s, (int)mp, (int)pb, Wp, ldv, T + j0 * ldt + j0, ldt,
+                               R + j0 * ldr + j0, ldr, reinterpret_cast<slot_t*>(q.Part), reinterpret_cast<slot_t*>(q.RowBuf),
+                               call_tag + (unsigned long long)(j0 / PB) * 64);
             NPW_LAUNCH_CHECK();
         } else {
             const int G = (int)ceil_div(mp, SLAB);
