@@ -617,10 +617,11 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_panel_kernel(int n, double
                                                                    double* Winv, int m_below, int* ready, int ready_val) {
     extern __shared__ __attribute__((aligned(16))) double S[];
     if (blockIdx.x == 0) {
-        // inv(L_jj) is written through (coherent stores); the barrier's s_waitcnt makes every wave's stores
-        // complete before thread 0 raises the flag.  No release fence: on this multi-die part that would write
+        // inv(L_jj) is written through (coherent stores); every wave waits for its own stores to be acknowledged
+        // and the barrier orders all of them before thread 0 raises the flag.  No release fence: on this multi-die part that would write
         // back the whole dirty L2 of the XCD (tens of microseconds after a GEMM).
         diag_block(n, A, lda, info, base, Winv, S, true);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have been acknowledged
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(ready, ready_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
