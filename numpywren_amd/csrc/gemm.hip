@@ -43,6 +43,7 @@ struct MfmaTraits<double> {
     using vec_t = d2_t;  // 16-byte chunk
     static constexpr int VEC = 2;
     static constexpr int PADK = 0;  // KC rows are not padded: 16-byte chunks are XOR-swizzled instead (kc_off)
+    static constexpr int PAD_MC = 8;
     __device__ static inline acc_t mfma(double a, double b, acc_t c) {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
     }
@@ -55,7 +56,8 @@ struct MfmaTraits<float> {
     using acc_t = f4_t;
     using vec_t = f4_t;
     static constexpr int VEC = 4;
-    static constexpr int PADK = 4;
+    static constexpr int PADK = 0;
+    static constexpr int PAD_MC = 4;
     __device__ static inline acc_t mfma(float a, float b, acc_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
     }
@@ -63,28 +65,29 @@ struct MfmaTraits<float> {
 };
 
 // k index inside a BK tile consumed by lane group g at MFMA step s.  Any bijection works as long as A and B
-// agree: steps (2p, 2p+1) of lane group g use the adjacent pair k = 8p + 2g, 8p + 2g + 1, so a KC fragment for
-// two steps is ONE load (ds_read_b128 for fp64, ds_read_b64 for fp32).
+// agree: VEC consecutive steps of lane group g use VEC adjacent k (VEC = elements per 16 bytes), so a KC fragment
+// for VEC steps is ONE ds_read_b128.
 template <typename T>
 __device__ inline int k_of(int s, int g) {
-    return 8 * (s >> 1) + 2 * g + (s & 1);
+    constexpr int VEC = MfmaTraits<T>::VEC;
+    return (s / VEC) * (4 * VEC) + VEC * g + (s % VEC);
 }
 
-// Element offset of (row, k) inside a KC tile (`Xs[row][k]`).  fp32: padded rows.  fp64: rows of exactly BK
-// elements whose 16-byte chunks are XOR-swizzled with the row number.  The padded fp64 layout (ld = BK + 2) was
-// conflict-free for ds_read_b64, but hipcc fuses the two fragment loads of consecutive steps into ds_read2_b64,
-// which is serviced in 16-lane groups over 32 banks at half the rate: PMC showed 39 % of the LDS cycles of the
-// trailing update as bank conflicts.  With the k pairing above a fragment pair is one ds_read_b128 (16-lane groups
-// {0-3,12-15,20-27},...: rows li and lane groups g, g+1 mixed), and chunk ^ f(row) makes each group cover all 64
-// banks exactly once; the 8-lane groups of ds_write_b128 stay inside one row and are conflict-free as well.
+// Element offset of (row, k) inside a KC tile (`Xs[row][k]`): rows of exactly BK elements whose 16-byte chunks are
+// XOR-swizzled with the row number.  (A padded layout that is conflict-free for ds_read_b64 does not survive
+// hipcc fusing the fragment loads of consecutive steps into ds_read2_b64, which is serviced in 16-lane groups
+// over 32 banks at half the rate: PMC showed ~40 % of the LDS cycles of the fp64 and fp32 kernels as bank
+// conflicts.)  A fragment is one ds_read_b128, whose 16-lane groups {0-3,12-15,20-27},... mix rows li and
+// lane groups g, g+1; chunk ^ f(row) makes each group cover all 64 banks exactly once, and the 8-lane groups of
+// ds_write_b128 stay conflict-free.  f depends on the chunks per row: 4 -> -(row>>2) & 3, 8 -> (row>>1) & 7,
+// 16 -> row & 15 (checked by enumeration against the bank rules of MI355X_MICROARCH.md).
 template <typename T, int BK>
 __device__ inline int kc_off(int row, int k) {
-    if constexpr (sizeof(T) == 8 && (BK == 16 || BK == 32)) {
-        const int f = (BK == 16) ? ((row >> 1) & 7) : (row & 15);
-        return row * BK + ((((k >> 1) ^ f) << 1) | (k & 1));
-    } else {
-        return row * (BK + MfmaTraits<T>::PADK) + k;
-    }
+    constexpr int VEC = MfmaTraits<T>::VEC;
+    constexpr int CPR = BK / VEC;
+    static_assert(CPR == 4 || CPR == 8 || CPR == 16, "kc_off: unsupported k-tile depth");
+    const int f = (CPR == 4) ? ((-(row >> 2)) & 3) : (CPR == 8) ? ((row >> 1) & 7) : (row & 15);
+    return row * BK + ((((k / VEC) ^ f) * VEC) | (k % VEC));
 }
 
 template <typename T>
@@ -176,13 +179,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
     constexpr int TM = WM / 16, TN = WN / 16;
     constexpr int KSTEPS = BK / 4;
     constexpr int LDKC = BK + TR::PADK;
-    constexpr int LDA_MC = BM + 16, LDB_MC = BN + 16;
+    // MC row stride: VEC-step fragments read rows VEC apart in neighbouring lane groups; + 16 B / + 32 B of padding
+    // (fp32 / fp64) puts them on disjoint banks
+    constexpr int LDA_MC = BM + TR::PAD_MC, LDB_MC = BN + TR::PAD_MC;
     constexpr int A_ELEMS = A_KC ? BM * LDKC : BK * LDA_MC;
     constexpr int B_ELEMS = B_KC ? BN * LDKC : BK * LDB_MC;
     constexpr int A_CHUNKS = BM * BK / VEC / 256;
     constexpr int B_CHUNKS = BN * BK / VEC / 256;
     static_assert(A_CHUNKS >= 1 && B_CHUNKS >= 1, "tile too small for 256 threads");
-    static_assert(BK % 8 == 0, "BK");
+    static_assert(BK % 8 == 0 && KSTEPS % VEC == 0, "BK");
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* smem = reinterpret_cast<T*>(smem_raw);
@@ -311,61 +316,35 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
     auto compute = [&](int buf) {
         const T* a_s = smem + buf * STAGE;
         const T* b_s = smem + buf * STAGE + A_ELEMS;
-        if constexpr (sizeof(T) == 8) {
-            // two MFMA steps per fragment load: k = kk, kk + 1 are adjacent (one 16-byte LDS read for KC operands)
+        // VEC MFMA steps per fragment load: their k are adjacent (one 16-byte LDS read for KC operands)
 #pragma unroll
-            for (int s = 0; s < KSTEPS; s += 2) {
-                const int kk = k_of<T>(s, lg);
-                vec_t af[TM], bf[TN];
+        for (int s = 0; s < KSTEPS; s += VEC) {
+            const int kk = k_of<T>(s, lg);
+            vec_t af[TM], bf[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    if constexpr (A_KC) {
-                        af[i] = *reinterpret_cast<const vec_t*>(&a_s[kc_off<T, BK>(wm0 + 16 * i + li, kk)]);
-                    } else {
-                        af[i][0] = a_s[kk * LDA_MC + wm0 + 16 * i + li];
-                        af[i][1] = a_s[(kk + 1) * LDA_MC + wm0 + 16 * i + li];
-                    }
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (A_KC) {
+                    af[i] = *reinterpret_cast<const vec_t*>(&a_s[kc_off<T, BK>(wm0 + 16 * i + li, kk)]);
+                } else {
+#pragma unroll
+                    for (int h = 0; h < VEC; ++h) af[i][h] = a_s[(kk + h) * LDA_MC + wm0 + 16 * i + li];
                 }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if constexpr (B_KC) {
-                        bf[j] = *reinterpret_cast<const vec_t*>(&b_s[kc_off<T, BK>(wn0 + 16 * j + li, kk)]);
-                    } else {
-                        bf[j][0] = b_s[kk * LDB_MC + wn0 + 16 * j + li];
-                        bf[j][1] = b_s[(kk + 1) * LDB_MC + wn0 + 16 * j + li];
-                    }
-                }
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) acc[i][j] = TR::mfma(af[i][h], bf[j][h], acc[i][j]);
             }
-        } else {
 #pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) {
-                const int kk = k_of<T>(s, lg);
-                T af[TM], bf[TN];
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (B_KC) {
+                    bf[j] = *reinterpret_cast<const vec_t*>(&b_s[kc_off<T, BK>(wn0 + 16 * j + li, kk)]);
+                } else {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    if constexpr (A_KC)
-                        af[i] = a_s[kc_off<T, BK>(wm0 + 16 * i + li, kk)];
-                    else
-                        af[i] = a_s[kk * LDA_MC + wm0 + 16 * i + li];
+                    for (int h = 0; h < VEC; ++h) bf[j][h] = b_s[(kk + h) * LDB_MC + wn0 + 16 * j + li];
                 }
+            }
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if constexpr (B_KC)
-                        bf[j] = b_s[kc_off<T, BK>(wn0 + 16 * j + li, kk)];
-                    else
-                        bf[j] = b_s[kk * LDB_MC + wn0 + 16 * j + li];
-                }
+            for (int h = 0; h < VEC; ++h)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = TR::mfma(af[i], bf[j], acc[i][j]);
-            }
+                    for (int j = 0; j < TN; ++j) acc[i][j] = TR::mfma(af[i][h], bf[j][h], acc[i][j]);
         }
     };
 
@@ -433,8 +412,8 @@ template <typename T, int BM, int BN, int BK, bool A_KC, bool B_KC, bool EDGE>
 int launch(const GemmParams<T>& p, hipStream_t stream) {
     using TR = MfmaTraits<T>;
     constexpr int LDKC = BK + TR::PADK;
-    constexpr int A_ELEMS = A_KC ? BM * LDKC : BK * (BM + 16);
-    constexpr int B_ELEMS = B_KC ? BN * LDKC : BK * (BN + 16);
+    constexpr int A_ELEMS = A_KC ? BM * LDKC : BK * (BM + TR::PAD_MC);
+    constexpr int B_ELEMS = B_KC ? BN * LDKC : BK * (BN + TR::PAD_MC);
     constexpr size_t smem = 2 * (A_ELEMS + B_ELEMS) * sizeof(T);
     // lower_only == 2: only the tiles touching the lower triangle are launched (see block_to_tile_tri)
     const int nwg = (p.lower_only == 2)   ? p.tiles_m * (p.tiles_m + 1) / 2
