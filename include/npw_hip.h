@@ -122,11 +122,14 @@ int npw_sgemm(char transA, char transB, int64_t m, int64_t n, int64_t k, float a
  * X == Y (same pointer and ld, m == n >= 256: the diagonal tiles of the trailing matrix): X X^T is
  * symmetric bit for bit, so only the tiles touching the lower triangle are computed and the strict
  * upper triangle of D is their transpose; S is then assumed symmetric (its lower triangle wins).
+ * workspace: npw_dgemm_nt_sub_workspace_bytes(m, n, k) bytes (0 unless the symmetric path applies), may
+ * be NULL: it lets the diagonal blocks of the symmetric path run k-split over the whole chip.
  * Replaces kernels.syrk (reference numpywren/kernels.py:212-215) -- the Cholesky
  * trailing update, the north-star kernel.                                      */
+size_t npw_dgemm_nt_sub_workspace_bytes(int64_t m, int64_t n, int64_t k);
 int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t lds,
                      const double* X, int64_t ldx, const double* Y, int64_t ldy, double* D,
-                     int64_t ldd, const int32_t* skip_x, const int32_t* skip_y,
+                     int64_t ldd, const int32_t* skip_x, const int32_t* skip_y, void* workspace,
                      npw_stream_t stream);
 
 /* Solve X * L^T = B for X, L lower triangular n x n (non-unit), B and X m x n.

@@ -62,7 +62,8 @@ PROTOTYPES = {
                           _i64, _vp, _vp]),
     "npw_sgemm": (c_int, [c_char, c_char, _i64, _i64, _i64, c_float, _vp, _i64, _vp, _i64, c_float, _vp, _i64, _vp,
                           _i64, _vp, _vp]),
-    "npw_dgemm_nt_sub": (c_int, [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "npw_dgemm_nt_sub_workspace_bytes": (c_size_t, [_i64, _i64, _i64]),
+    "npw_dgemm_nt_sub": (c_int, [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "npw_dtrsm_rltn_workspace_bytes": (_sz, [_i64, _i64]),
     "npw_dtrsm_rltn": (c_int, [_i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "npw_dtrtri_diag_bytes": (_sz, [_i64]),

@@ -460,7 +460,11 @@ int dispatch_layout(bool a_kc, bool b_kc, const GemmParams<T>& p, hipStream_t s)
 // D = alpha * sum_s P[s] + beta * C over the split-K partial products P[s] (each m x n, contiguous)
 template <typename T>
 __global__ void splitk_reduce_kernel(int nsplit, const T* P, int64_t stride, int64_t m, int64_t n, T alpha, T beta,
-                                     const T* C, int64_t ldc, T* D, int64_t ldd) {
+                                     const T* C, int64_t ldc, T* D, int64_t ldd, int64_t batch_c, int64_t batch_d) {
+    // blockIdx.z = problem of a batch: its partials are contiguous (nsplit * stride), C / D move by the batch strides
+    P += (int64_t)blockIdx.z * nsplit * stride;
+    if (C) C += (int64_t)blockIdx.z * batch_c;
+    D += (int64_t)blockIdx.z * batch_d;
     for (int64_t r = blockIdx.y; r < m; r += gridDim.y)
         for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (int64_t)gridDim.x * blockDim.x) {
             T acc = T(0);
@@ -524,13 +528,19 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
             GemmOpts inner = opts;
             inner.splitk = 1;
             inner.k_chunk_ = (int)chunk;
+            inner.lower_only = false;  // the reduction reads every element of the partial products
+            inner.strict_lower = false;
+            inner.batch_c = inner.batch2_c = 0;
+            inner.batch_d = (int64_t)nsplit * m * n;  // partials of one problem are contiguous
+            inner.batch2_d = 0;
+            NPW_REQUIRE(opts.batch_inner == 0, "gemm: split-K with a two-level batch is not supported");
             T* P = static_cast<T*>(opts.splitk_ws);
             int rc = gemm<T>(transA, transB, m, n, k, T(1), A, lda, B, ldb, T(0), nullptr, 0, P, n, inner, stream);
             if (rc) return rc;
             const unsigned gx = (unsigned)(ceil_div(n, 256) > 16 ? 16 : ceil_div(n, 256));
             const unsigned gy = (unsigned)(m > 1024 ? 1024 : m);
-            hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(gx, gy), dim3(256), 0, stream, nsplit, P, m * n, m, n, alpha,
-                               beta, C, ldc, D, ldd);
+            hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(gx, gy, (unsigned)opts.batch), dim3(256), 0, stream, nsplit, P,
+                               m * n, m, n, alpha, beta, C, ldc, D, ldd, opts.batch_c, opts.batch_d);
             NPW_LAUNCH_CHECK();
             return NPW_OK;
         }
@@ -554,7 +564,7 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
     p.skip1 = opts.skip1;
     p.lower_only = opts.lower_only ? (m == n && !opts.inplace_a ? (opts.strict_lower ? 3 : 2) : 1) : 0;
     NPW_REQUIRE(!opts.strict_lower || p.lower_only == 3, "gemm: strict_lower needs a square lower_only product");
-    NPW_REQUIRE(opts.batch >= 1 && (opts.batch == 1 || opts.k_chunk_ == 0), "gemm: bad batch");
+    NPW_REQUIRE(opts.batch >= 1, "gemm: bad batch");
     p.tiles_batch = opts.batch;
     p.batch_a = opts.batch_a;
     p.batch_b = opts.batch_b;
@@ -648,9 +658,19 @@ int npw_sgemm(char transA, char transB, int64_t m, int64_t n, int64_t k, float a
                             npw::as_stream(stream));
 }
 
+namespace {
+constexpr int kDiagSplit = 8;  // k chunks of the diagonal-block launch of the symmetric trailing update
+bool nt_sub_symmetric_split(int64_t m, int64_t n) { return m == n && m % 128 == 0 && m >= 2048; }
+}  // namespace
+
+size_t npw_dgemm_nt_sub_workspace_bytes(int64_t m, int64_t n, int64_t k) {
+    if (!nt_sub_symmetric_split(m, n) || k < 1024) return 0;
+    return (size_t)(m / 128) * kDiagSplit * 128 * 128 * sizeof(double);
+}
+
 int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t lds,
                      const double* X, int64_t ldx, const double* Y, int64_t ldy, double* D,
-                     int64_t ldd, const int32_t* skip_x, const int32_t* skip_y,
+                     int64_t ldd, const int32_t* skip_x, const int32_t* skip_y, void* workspace,
                      npw_stream_t stream) {
     npw::GemmOpts o;
     o.skip0 = skip_x;
@@ -667,7 +687,7 @@ int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t l
     o.tag = 2;
     o.lower_only = true;
     int rc;
-    if (m % 128 == 0 && m >= 2048) {
+    if (nt_sub_symmetric_split(m, n)) {
         // 2 workgroups share a CU, so the chip holds 512 tiles at a time: the 496 strictly-lower tiles of a
         // 4096^2 output are one full wave of work, the 32 diagonal tiles would be a second, nearly empty one.
         // They go into their own small batched launch (lower 64 x 64 sub-tiles only) instead.
@@ -682,6 +702,14 @@ int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t l
         d.batch_a = d.batch_b = 128 * ldx;
         d.batch_c = 128 * (lds + 1);
         d.batch_d = 128 * (ldd + 1);
+        if (workspace != nullptr && npw_dgemm_nt_sub_workspace_bytes(m, n, k) > 0) {
+            // 96 workgroups with the full k would run alone for 0.18 ms: cut k into chunks (8x the workgroups,
+            // partial products summed in a fixed order)
+            NPW_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "npw_dgemm_nt_sub: workspace not 16B aligned");
+            d.lower_only = false;
+            d.splitk = kDiagSplit;
+            d.splitk_ws = workspace;
+        }
         rc = npw::gemm<double>('N', 'T', 128, 128, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, d, npw::as_stream(stream));
     } else {
         rc = npw::gemm<double>('N', 'T', m, n, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, o, npw::as_stream(stream));

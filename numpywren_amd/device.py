@@ -562,10 +562,16 @@ class HipBackend(object):
         self._use(sh, S, X, Y, out)
         # X is Y on the diagonal tiles: the library then computes the lower tiles only and mirrors them
         tname = "syrk_sym" if (X.ptr == Y.ptr and m == n and m >= 256) else "syrk"
+        ws = None
+        if X.ptr == Y.ptr:
+            nbytes = self.lib.npw_dgemm_nt_sub_workspace_bytes(m, n, k)
+            if nbytes:
+                ws = self.alloc(nbytes)
+                ws.streams.add(sh)
         t0 = self._tic(tname, sh)
         _ffi.check(self.lib.npw_dgemm_nt_sub(m, n, k, S.ptr, n, X.ptr, k, Y.ptr, k, out.ptr, n,
                                              fx.ptr if fx is not None else None, fy.ptr if fy is not None else None,
-                                             sh), "syrk")
+                                             ws.ptr if ws is not None else None, sh), "syrk")
         self._toc(tname, sh, t0)
         self._produced(sh, out)
         return out

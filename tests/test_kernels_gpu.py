@@ -101,7 +101,7 @@ def test_cholesky_chain_vs_oracle(b):
     np.testing.assert_allclose(kernels.syrk(S, X, Y), oracle.syrk(S, X, Y), rtol=0, atol=1e-12 * b)
 
 
-@pytest.mark.parametrize("n,k", [(256, 96), (384, 64), (2048, 128), (2176, 64)])
+@pytest.mark.parametrize("n,k", [(256, 96), (384, 64), (2048, 128), (2176, 64), (2048, 1024)])
 def test_syrk_same_operand_is_bitwise_the_full_product(n, k):
     """x is y (diagonal tiles of the trailing matrix): lower tiles + mirror == the full S - X Y^T, bit for bit."""
     from numpywren_amd.device import get_backend
@@ -113,7 +113,14 @@ def test_syrk_same_operand_is_bitwise_the_full_product(n, k):
     S, X, Xc = be.to_device(Sh), be.to_device(Xh), be.to_device(Xh)
     sym = be.to_host(be.syrk(S, X, X))
     full = be.to_host(be.syrk(S, X, Xc))          # distinct buffers -> general path
-    assert np.array_equal(sym, full)
+    if n >= 2048 and k >= 1024:
+        # the 128 x 128 diagonal blocks are summed k-split (fixed order): same values to rounding, everything
+        # else bit for bit
+        blk = np.kron(np.eye(n // 128), np.ones((128, 128))).astype(bool)
+        assert np.array_equal(sym[~blk], full[~blk])
+        np.testing.assert_allclose(sym[blk], full[blk], rtol=0, atol=1e-12 * k)
+    else:
+        assert np.array_equal(sym, full)
     assert np.array_equal(sym, sym.T)
     np.testing.assert_allclose(sym, oracle.syrk(Sh, Xh, Xh), rtol=0, atol=1e-12 * k)
     z = be.zeros((n, k))                            # allclose(x, 0) short-circuit keeps s
