@@ -475,22 +475,25 @@ __device__ inline void diag_block(int n, double* A, int64_t lda, int32_t* info, 
             } else {
                 invert_diag16(S, Wd, jb, lane);
             }
+            if (wave >= 2) {
+                // Block column jb of the 128 x 128 block is final (L below the diagonal sub-block, zeros above it):
+                // waves 2..7 send it home now, 8-row groups dealt round robin.  Asynchronous stores beside the next
+                // column's factorisation -- a separate store pass at the end cost 2.5 us per block.
+                const int cp = jb * JB + (lane & 7) * 2;
+                const bool vec = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((lda & 1) == 0);
+                for (int r = (wave - 2) * 8 + (lane >> 3); r < n; r += 48) {
+                    if (vec && cp + 1 < n) {
+                        *reinterpret_cast<double2*>(&A[(int64_t)r * lda + cp]) = *reinterpret_cast<const double2*>(&S[r * SLD + cp]);
+                    } else {
+                        if (cp < n) A[(int64_t)r * lda + cp] = S[r * SLD + cp];
+                        if (cp + 1 < n) A[(int64_t)r * lda + cp + 1] = S[r * SLD + cp + 1];
+                    }
+                }
+            }
         }
     }
     __syncthreads();
     NPW_STAMP(18)
-
-    // L back to global: lower triangle, zeros above
-    {
-        const int c = tid & (NB - 1), r0 = tid >> 7;
-        if (c < n) {
-#pragma unroll 8
-            for (int i = 0; i < NB * NB / DIAG_THREADS; ++i) {
-                const int r = r0 + (DIAG_THREADS / NB) * i;
-                if (r < n) A[(int64_t)r * lda + c] = (c <= r) ? S[r * SLD + c] : 0.0;
-            }
-        }
-    }
     if (failed) {
         for (int idx = tid; idx < NB * NB; idx += DIAG_THREADS)
             __hip_atomic_store(&Winv[(idx / NB) * LW + (idx % NB)], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
