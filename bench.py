@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense fp64 matrix peak (vendor spec; 74.6 measured by tools/devcheck)
 TILE = 4096
-SYRK_TRAFFIC_BYTES = 2.077e9    # measured, see profiles/r01_bench_rocprof_summary.md
+SYRK_TRAFFIC_BYTES = 2.27e9    # measured, see profiles/r01_bench_rocprof_summary.md
 TILES_PER_SIDE = {1: 4, 2: 8, 4: 12, 8: 16}
 
 
