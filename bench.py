@@ -145,7 +145,19 @@ def main():
         program._priorities()
         prebuilt.append((program, meta))
 
+    pending = []   # (program, meta) enqueued on the device, not yet waited for
+
+    def settle():
+        while pending:
+            program, _ = pending.pop(0)
+            program.wait()
+            if program.program_status() != lp.PS.SUCCESS:
+                raise SystemExit(f"cholesky failed: {program.exceptions}")
+
     def one_step():
+        """One factorisation.  On one GPU the step is enqueued and the PREVIOUS one is waited for afterwards
+        (program.wait() is where the reference's call sequence waits, too), so the host-side turnaround between two
+        factorisations does not leave the GPU idle; every step is complete before the closing barrier."""
         program, meta = prebuilt.pop(0)
         for m in meta["outputs"] + meta["intermediates"]:
             m.free()
@@ -153,15 +165,18 @@ def main():
         program.config["executor"]["priority_stream"] = args.priority_stream
         program.start()
         if comm is None:
-            job_runner.lambdapack_run(program, pipeline_width=args.streams, timeout=3600)
+            job_runner.lambdapack_run(program, pipeline_width=args.streams, timeout=3600, wait=False)
+            settle()
+            pending.append((program, meta))
         else:
             from numpywren_amd import dist
             dist.lambdapack_run_distributed(program, comm, pipeline_width=args.streams, timeout=3600)
-        if program.program_status() != lp.PS.SUCCESS:
-            raise SystemExit(f"cholesky failed: {program.exceptions}")
+            if program.program_status() != lp.PS.SUCCESS:
+                raise SystemExit(f"cholesky failed: {program.exceptions}")
         return meta
 
     def barrier():
+        settle()
         if comm is not None:
             comm.barrier()
         be.synchronize()

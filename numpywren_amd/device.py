@@ -514,6 +514,24 @@ class HipBackend(object):
         self.stream_sync(sh)
         return int(out[0])
 
+    def flag_stream(self):
+        """A stream nothing else is enqueued on: host reads of flags that are known to be final (the caller has waited
+        for their producer) must not queue behind later work of a pipelining caller."""
+        if getattr(self, "_flag_stream", None) is None:
+            self._flag_stream = self.create_stream(name="flags")
+        return self._flag_stream
+
+    def read_flags(self, flags, stream=None):
+        """Several device int32 flags with ONE stream synchronisation (read_flag costs a round trip apiece)."""
+        if not flags:
+            return []
+        sh = self._sh(stream)
+        out = np.zeros(len(flags), dtype=np.int32)
+        for i, f in enumerate(flags):
+            _ffi.check(self.lib.npw_memcpy_d2h_async(out.ctypes.data + 4 * i, f.ptr, 4, sh))
+        self.stream_sync(sh)
+        return [int(x) for x in out]
+
     def gemm(self, A, B, transpose_A=False, transpose_B=False, stream=None, alpha=1.0, beta=0.0, C=None, out=None,
              skip=None):
         """alpha * op(A) op(B) + beta * C -> new tile (or `out`).  fp64 or fp32 (both operands same dtype)."""

@@ -223,11 +223,15 @@ def _info_sink(program, task):
 lp.LambdaPackProgram.info_flags_sink = lambda self, task: _info_sink(self, task)
 
 
-def check_info_flags(program, be):
-    """Deferred np.linalg.LinAlgError: read back the Cholesky info flags of the run."""
+def check_info_flags(program, be, stream=None):
+    """Deferred np.linalg.LinAlgError: read back the Cholesky info flags of the run (the caller has synchronised with
+    their producers; `stream` only carries the copies)."""
     flags, program.info_flags = program.info_flags, []
-    for flag, node in flags:
-        code = be.read_flag(flag)
+    if hasattr(be, "read_flags"):
+        codes = be.read_flags([f for f, _ in flags], stream)
+    else:
+        codes = [be.read_flag(f) for f, _ in flags]
+    for (flag, node), code in zip(flags, codes):
         if code != 0:
             msg = "Matrix is not positive definite (leading minor of order {0} in task {1})".format(code, node)
             program.handle_exception(np.linalg.LinAlgError(msg), tb="", expr_idx=node[0], var_values=node[1])
@@ -236,12 +240,17 @@ def check_info_flags(program, be):
 
 
 def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, timeout=200, idle_timeout=5,
-                   msg_vis_timeout_jitter=15, compute_threads=1, max_inflight=64):
+                   msg_vis_timeout_jitter=15, compute_threads=1, max_inflight=64, wait=True):
     """Run `program` to completion (or until `timeout` seconds) on the local GPU.
 
     pipeline_width -> number of HIP streams; the SQS visibility / idle / thread arguments of the
     reference are accepted and ignored (no queue service, no worker fleet).  Returns the reference's
-    result dict."""
+    result dict.
+
+    wait=False returns as soon as every task has been enqueued on the device; `program.wait()` -- the next call of
+    the reference's sequence start / lambdapack_run / wait / free -- then synchronises, evaluates the deferred
+    LinAlgError flags and settles the status.  A caller that factors one matrix after another can enqueue the next
+    program before waiting for the previous one, so the GPU does not idle during the host-side turnaround."""
     program.incr_up(1)
     t_start = time.time()
     be = get_backend()
@@ -279,13 +288,36 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
                 inflight.append(last)
                 if len(inflight) > max_inflight:
                     be.wait_tile(inflight.popleft())
-        be.synchronize()
-        ok = check_info_flags(program, be)
+        # completion marks of THIS run: one event per stream it used (a device-wide synchronise would also wait for
+        # whatever a pipelining caller has enqueued behind it)
+        used = list(ex.streams) + ([ex.prio_stream] if ex.prio_stream is not None else [])
+        marks = [be.record_new(sh) for sh in used] if hasattr(be, "record_new") and hasattr(be, "event_sync") else None
+
+        def finish():
+            program._finish = None
+            try:
+                if marks is None or wait:
+                    be.synchronize()
+                    ok = check_info_flags(program, be)
+                else:
+                    for ev in marks:
+                        be.event_sync(ev)
+                        be.recycle_event(ev)
+                    ok = check_info_flags(program, be, be.flag_stream())
+                program._defer_success = False
+                if ok and program._success_pending and program.program_status() == lp.PS.RUNNING:
+                    program.return_success()
+            finally:
+                program._defer_success = False
+
+        if wait:
+            finish()
+        else:
+            program._finish = finish
+    except BaseException:
         program._defer_success = False
-        if ok and program._success_pending and program.program_status() == lp.PS.RUNNING:
-            program.return_success()
+        raise
     finally:
-        program._defer_success = False
         program.decr_up(1)
     t_stop = time.time()
     return {"up_time": [t_start, t_stop],

@@ -435,6 +435,9 @@ class LambdaPackProgram(object):
             return self._status
 
     def wait(self, sleep_time=1):
+        finish = getattr(self, "_finish", None)
+        if finish is not None:      # job_runner.lambdapack_run(..., wait=False): settle the run here
+            finish()
         status = self.program_status()
         while status == PS.RUNNING:
             time.sleep(sleep_time)

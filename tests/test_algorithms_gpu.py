@@ -300,3 +300,23 @@ def test_qr_golden(tag, b, hbm_store):
                                        err_msg=f"R[{i},{k}]")
     R = np.linalg.qr(Xh)[1]
     np.testing.assert_allclose(np.abs(Rs.get_block(0, 0, 0)), np.abs(R[:b, :b]), atol=1e-10)
+
+
+def test_two_factorisations_in_flight(hbm_store):
+    """enqueue a second program before waiting for the first (job_runner.lambdapack_run(wait=False))"""
+    rng = np.random.default_rng(17)
+    progs = []
+    for t in range(2):
+        G = rng.standard_normal((512, 512))
+        A = G @ G.T + 512 * np.eye(512)
+        X = BigMatrix(f"inflight_{t}", shape=A.shape, shard_sizes=(128, 128))
+        shard_matrix(X, A)
+        program, meta = alg_wrappers.cholesky(X)
+        program.start()
+        job_runner.lambdapack_run(program, wait=False)
+        progs.append((program, meta, A))
+    for program, meta, A in progs:
+        program.wait()
+        assert program.program_status() == lp.PS.SUCCESS
+        L = np.tril(meta["outputs"][0].numpy())
+        np.testing.assert_allclose(L, np.linalg.cholesky(A), rtol=1e-10, atol=1e-10)

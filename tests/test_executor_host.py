@@ -185,3 +185,27 @@ def test_qr(tag, b, oracle_backend):
         for k in range(i, nb):
             np.testing.assert_allclose(Rs.get_block(i, k, 0), QRG[f"qr_{tag}/R_{i}_{k}"], rtol=1e-9, atol=1e-9,
                                        err_msg=f"R[{i},{k}]")
+
+
+def test_run_without_waiting_settles_in_program_wait(oracle_backend):
+    """lambdapack_run(wait=False) only enqueues; program.wait() -- next in the reference's call sequence -- settles."""
+    A, L = ALG["cholesky_32_8/A"], ALG["cholesky_32_8/L"]
+    X = BigMatrix("nowait_A", shape=A.shape, shard_sizes=(8, 8))
+    shard_matrix(X, A)
+    program, meta = alg_wrappers.cholesky(X)
+    program.start()
+    res = job_runner.lambdapack_run(program, wait=False)
+    assert len(res["executed_messages"]) == 20
+    assert program.program_status() == lp.PS.RUNNING          # not settled yet
+    program.wait()
+    assert program.program_status() == lp.PS.SUCCESS
+    np.testing.assert_allclose(np.tril(meta["outputs"][0].numpy()), L, atol=1e-12)
+    program.wait()                                             # idempotent
+    bad = -np.eye(16)
+    Y = BigMatrix("nowait_bad", shape=bad.shape, shard_sizes=(8, 8))
+    shard_matrix(Y, bad)
+    program, meta = alg_wrappers.cholesky(Y)
+    program.start()
+    job_runner.lambdapack_run(program, wait=False)
+    program.wait()
+    assert program.program_status() == lp.PS.EXCEPTION

@@ -32,3 +32,14 @@ print("  big kernels (>0.3 ms):")
 for s, e, n, st, g in seg:
     if e - s > 300e3:
         print(f"    {(s-t0)/1e6:8.3f} -> {(e-t0)/1e6:8.3f}  {(e-s)/1e6:6.3f} ms stream {st} grid {g:5d} {n}")
+# idle gaps > 15 us inside the window
+prev_end = None
+gaps = []
+for s, e, n, st, g in seg:
+    if prev_end is not None and s - prev_end > 15e3:
+        gaps.append((s - prev_end, (prev_end - t0) / 1e6, n))
+    prev_end = max(prev_end or e, e)
+gaps.sort(reverse=True)
+print(f"  idle gaps > 15 us: {len(gaps)}, total {sum(g[0] for g in gaps)/1e6:.3f} ms")
+for d, at, n in gaps[:12]:
+    print(f"    {d/1e3:8.1f} us before {n} at {at:8.3f} ms")
