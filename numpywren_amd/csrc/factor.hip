@@ -8,7 +8,6 @@
 //   potrf(A):   right-looking over NB-wide block columns, three launches each:
 //               diagonal block (factor + invert, one workgroup, LDS-resident)  ->  panel P <- P inv(L_jj)^T
 //               (one in-place GEMM)  ->  trailing update A22 -= P P^T (one GEMM over the lower tiles only).
-//               (A recursive variant, potrf_rec, is kept behind NPW_POTRF_RECURSIVE=1 for comparison.)
 //   trsm(X,L):  recursive:  X1 = trsm(X1, L11);  X2 -= X1 * L21^T;  X2 = trsm(X2, L22)
 //               leaf:  X_j = X_j * inv(L_jj)^T   (GEMM with the cached inverse of the NB x NB diagonal block)
 //
@@ -766,32 +765,6 @@ int trsm_rec(const TrsmCtx& c, int64_t coff, int64_t n, bool touched) {
     return trsm_rec(c, coff + n1, n2, true);
 }
 
-// in-place Cholesky of the trailing n x n block of A starting at (off, off)
-int potrf_rec(int64_t n, int64_t off, double* A, int64_t lda, int32_t* info, double* Winv, double* T, hipStream_t s) {
-    double* Ab = A + off * lda + off;
-    if (n <= NB) {
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, s, (int)n, Ab, lda, info,
-                           (int)off, Winv + w_block_offset(off / NB));
-        NPW_LAUNCH_CHECK();
-        return NPW_OK;
-    }
-    const int64_t n1 = split(n), n2 = n - n1;
-    int rc = potrf_rec(n1, off, A, lda, info, Winv, T, s);
-    if (rc) return rc;
-    // A21 <- A21 * L11^-T : rows [off+n1, off+n), columns [off, off+n1), in place
-    double* A21 = A + (off + n1) * lda + off;
-    TrsmCtx c{n2, A, lda, A21, lda, A21, lda, T, n1, Winv, off, s};
-    rc = trsm_rec(c, 0, n1, false);
-    if (rc) return rc;
-    // A22 -= A21 A21^T (only tiles touching the lower triangle)
-    double* A22 = A + (off + n1) * lda + (off + n1);
-    GemmOpts o;
-    o.lower_only = true;
-    rc = gemm<double>('N', 'T', n2, n2, n1, -1.0, A21, lda, A21, lda, 1.0, A22, lda, A22, lda, o, s);
-    if (rc) return rc;
-    return potrf_rec(n2, off + n1, A, lda, info, Winv, T, s);
-}
-
 // Right-looking blocked Cholesky with NB-wide panels: three launches per block column
 //   diag block (factor + invert, one workgroup) -> panel  P <- P inv(L_jj)^T  (in place, one GEMM) ->
 //   trailing update  A22 -= P P^T  (lower tiles only, one GEMM with K = NB).
@@ -915,8 +888,7 @@ int npw_dtrsm_rltn(int64_t m, int64_t n, const double* L, int64_t ldl, const dou
 
 size_t npw_dpotrf_lower_workspace_bytes(int64_t n) {
     if (n <= 0) return 0;
-    const int64_t h = n - split(n);  // largest panel: (n - n1) x n1
-    return winv_bytes(n) + (size_t)h * (size_t)(n > NB ? split(n) : 0) * sizeof(double);
+    return winv_bytes(n);  // the block inverses (kept with the factor for its trsm consumers) + their scratch
 }
 
 int npw_dpotrf_lower(int64_t n, const double* A, int64_t lda, double* Lout, int64_t ldl,
@@ -942,13 +914,8 @@ int npw_dpotrf_lower(int64_t n, const double* A, int64_t lda, double* Lout, int6
         NPW_LAUNCH_CHECK();
     }
     double* Winv = static_cast<double*>(workspace);
-    double* T = reinterpret_cast<double*>(static_cast<char*>(workspace) + winv_bytes(n));
-    static const bool recursive = [] {
-        const char* e = getenv("NPW_POTRF_RECURSIVE");
-        return e && e[0] == '1';
-    }();
     NPW_HIP_CHECK(hipMemsetAsync(Winv, 0, winv_group_elems(n) * sizeof(double), s));
-    rc = recursive ? potrf_rec(n, 0, Lout, ldl, info_dev, Winv, T, s) : potrf_right(n, Lout, ldl, info_dev, Winv, s);
+    rc = potrf_right(n, Lout, ldl, info_dev, Winv, s);
     if (rc) return rc;
     return complete_groups(n, Lout, ldl, Winv, s);  // the factor's trsm consumers use LW-wide leaves
 }
