@@ -107,7 +107,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tiles", type=int, default=0, help="tiles per side (default: by GPU count)")
     ap.add_argument("--tile", type=int, default=TILE)
-    ap.add_argument("--streams", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=0,
+                    help="HIP streams per rank (0 = 1 on one GPU, 3 with several: a task waiting for a tile in "
+                         "transit must not block the tasks behind it)")
     ap.add_argument("--priority-stream", action="store_true", help="panel kernels on a high-priority stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -117,6 +119,8 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     os.environ.pop("NUMPYWREN_AMD_STORE", None)
+    if args.streams <= 0:
+        args.streams = 1 if world == 1 else 3
 
     from numpywren_amd import alg_wrappers, job_runner
     from numpywren_amd import lambdapack as lp
