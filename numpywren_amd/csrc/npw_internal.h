@@ -65,4 +65,12 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
          int64_t lda, const T* B, int64_t ldb, T beta, const T* C, int64_t ldc, T* D, int64_t ldd,
          const GemmOpts& opts, hipStream_t stream);
 
+// A helper stream + two events attached to a caller stream, for fork/join of independent launches inside one
+// C-ABI call (created on first use, one per caller stream and host thread, never destroyed).
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+int side_stream(hipStream_t main, SideStream** out);
+
 }  // namespace npw

@@ -255,6 +255,7 @@ struct QrWorkspace {
     double* Tmp;  // (n/2 rounded up) x n
     double* Part;    // 2 x slabs x PB hand-off slots (16 bytes each) of the panel kernel
     double* RowBuf;  // 2 x PB slots: the next pivot row
+    double* Xn;      // (2 + 32) x PB x PB: scratch (X1, X2, split-K partials) of the look-ahead update
 };
 
 inline size_t align2(size_t x) { return (x + 1) & ~(size_t)1; }
@@ -273,6 +274,8 @@ QrWorkspace carve(void* ws, int64_t m, int64_t n) {
     q.Part = p;
     p += align2((size_t)4 * ceil_div(m, SLAB) * PB);
     q.RowBuf = p;
+    p += 4 * PB;
+    q.Xn = p;
     return q;
 }
 
@@ -297,6 +300,31 @@ int merge_t(int64_t lo, int64_t hi, double* T, int64_t ldt, const double* G, int
                         T + lo * ldt + mid, ldt, GemmOpts(), s);
 }
 
+// W2 (mp x nc, ld ldv) -= V_p (T_p^T (V_p^T W2)), then its top pb rows (final rows of R) move to Rdst and are
+// zeroed in place (V is zero there).  X1, X2: pb x nc scratch; skws: optional split-K scratch of skcap elements.
+int apply_panel(const double* Wp, int64_t ldv, int64_t mp, int64_t pb, const double* Tjj, int64_t ldt, double* W2,
+                int64_t nc, double* X1, double* X2, double* skws, size_t skcap, double* Rdst, int64_t ldr, hipStream_t s) {
+    // X1 = V_p^T W2 is pb x nc with a contraction over all mp rows: split k so that the launch has a few hundred
+    // workgroups instead of nc/64
+    GemmOpts sk;
+    int64_t want = 512 / (ceil_div(nc, 64) > 0 ? ceil_div(nc, 64) : 1);
+    if (want > mp / 256) want = mp / 256;
+    if (want > 32) want = 32;
+    if (skws != nullptr && want > 1 && (size_t)want * pb * nc <= skcap) {
+        sk.splitk = (int)want;
+        sk.splitk_ws = skws;
+    }
+    int rc = gemm<double>('T', 'N', pb, nc, mp, 1.0, Wp, ldv, W2, ldv, 0.0, nullptr, 0, X1, nc, sk, s);
+    if (rc) return rc;
+    rc = gemm<double>('T', 'N', pb, nc, pb, 1.0, Tjj, ldt, X1, nc, 0.0, nullptr, 0, X2, nc, GemmOpts(), s);
+    if (rc) return rc;
+    rc = gemm<double>('N', 'N', mp, nc, pb, -1.0, Wp, ldv, X2, nc, 1.0, W2, ldv, W2, ldv, GemmOpts(), s);
+    if (rc) return rc;
+    NPW_HIP_CHECK(hipMemcpy2DAsync(Rdst, ldr * 8, W2, ldv * 8, nc * 8, pb, hipMemcpyDeviceToDevice, s));
+    NPW_HIP_CHECK(hipMemset2DAsync(W2, ldv * 8, 0, nc * 8, pb, s));
+    return NPW_OK;
+}
+
 }  // namespace
 }  // namespace npw
 
@@ -308,7 +336,7 @@ size_t npw_dgeqrt_workspace_bytes(int64_t m, int64_t n) {
     if (m <= 0 || n <= 0) return 0;
     const size_t doubles = 2 * align2((size_t)PB * n) + align2((size_t)n * n) +
                            align2((size_t)((n + 1) / 2 + PB) * n) + align2((size_t)4 * ceil_div(m, SLAB) * PB) +
-                           4 * PB;
+                           4 * PB + 34 * PB * PB;
     return doubles * sizeof(double);
 }
 
@@ -336,6 +364,12 @@ int npw_dgeqrt(int64_t m, int64_t n, const double* A, int64_t lda, double* V, in
     static std::atomic<unsigned long long> call_counter{
         (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() & 0x3fffffffULL};
     const unsigned long long call_tag = (call_counter.fetch_add(1) + 1) << 24;
+    SideStream* side = nullptr;
+    {
+        int rc = side_stream(s, &side);
+        if (rc) return rc;
+        NPW_HIP_CHECK(hipEventRecord(side->join, s));  // so that the closing wait is valid for a single panel
+    }
     for (int64_t j0 = 0; j0 < n; j0 += PB) {
         const int64_t pb = (n - j0 < PB) ? n - j0 : PB;
         const int64_t mp = m - j0;
@@ -349,30 +383,26 @@ int npw_dgeqrt(int64_t m, int64_t n, const double* A, int64_t lda, double* V, in
         }
         const int64_t n2 = n - j0 - pb;
         if (n2 > 0) {
+            // Trailing update  W2 -= V_p (T_p^T (V_p^T W2))  with look-ahead: the next panel's columns are updated on
+            // the caller's stream, so the next panel kernel (latency-bound, <= 32 small workgroups) can start while
+            // the side stream updates the rest of the trailing matrix with chip-filling GEMMs.
             double* W2 = Wp + pb;
-            // X1 = V_p^T W2 is 32 x n2 with a contraction over all mp rows: split k so that the launch has
-            // a few hundred workgroups instead of n2/64 (the V^T V buffer is free until the panels are done)
-            GemmOpts sk;
-            int64_t want = 512 / (ceil_div(n2, 64) > 0 ? ceil_div(n2, 64) : 1);
-            if (want > mp / 256) want = mp / 256;
-            if (want > 32) want = 32;
-            if (want > 1 && (size_t)want * pb * n2 <= (size_t)n * n) {
-                sk.splitk = (int)want;
-                sk.splitk_ws = q.G;
+            const int64_t nn = (n2 < PB) ? n2 : PB;  // columns of the next panel
+            if (j0 > 0) NPW_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));  // rest(j-1) touched these columns
+            int rc = apply_panel(Wp, ldv, mp, pb, T + j0 * ldt + j0, ldt, W2, nn, q.Xn, q.Xn + PB * PB, q.Xn + 2 * PB * PB,
+                                 (size_t)32 * PB * PB, R + j0 * ldr + j0 + pb, ldr, s);
+            if (rc) return rc;
+            if (n2 > nn) {
+                NPW_HIP_CHECK(hipEventRecord(side->fork, s));
+                NPW_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+                rc = apply_panel(Wp, ldv, mp, pb, T + j0 * ldt + j0, ldt, W2 + nn, n2 - nn, q.X1, q.X2, q.G,
+                                 (size_t)n * n, R + j0 * ldr + j0 + pb + nn, ldr, side->stream);
+                if (rc) return rc;
             }
-            int rc = gemm<double>('T', 'N', pb, n2, mp, 1.0, Wp, ldv, W2, ldv, 0.0, nullptr, 0, q.X1, n2, sk, s);
-            if (rc) return rc;
-            rc = gemm<double>('T', 'N', pb, n2, pb, 1.0, T + j0 * ldt + j0, ldt, q.X1, n2, 0.0, nullptr, 0, q.X2,
-                              n2, GemmOpts(), s);
-            if (rc) return rc;
-            rc = gemm<double>('N', 'N', mp, n2, pb, -1.0, Wp, ldv, q.X2, n2, 1.0, W2, ldv, W2, ldv, GemmOpts(), s);
-            if (rc) return rc;
-            // rows j0 .. j0+pb of the updated trailing block are final rows of R; V is zero there
-            NPW_HIP_CHECK(hipMemcpy2DAsync(R + j0 * ldr + j0 + pb, ldr * 8, W2, ldv * 8, n2 * 8, pb,
-                                           hipMemcpyDeviceToDevice, s));
-            NPW_HIP_CHECK(hipMemset2DAsync(W2, ldv * 8, 0, n2 * 8, pb, s));
+            NPW_HIP_CHECK(hipEventRecord(side->join, side->stream));
         }
     }
+    NPW_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
     if (n > PB) {
         // G = V^T V, then the off-diagonal blocks of T bottom-up
         int rc = gemm<double>('T', 'N', n, n, m, 1.0, V, ldv, V, ldv, 0.0, nullptr, 0, q.G, n, GemmOpts(), s);

@@ -25,6 +25,22 @@ int set_error(int code, const char* fmt, ...) {
 
 using npw::as_stream;
 
+#include <unordered_map>
+
+namespace npw {
+int side_stream(hipStream_t main, SideStream** out) {
+    static thread_local std::unordered_map<hipStream_t, SideStream> table;
+    SideStream& e = table[main];
+    if (e.stream == nullptr) {
+        NPW_HIP_CHECK(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
+        NPW_HIP_CHECK(hipEventCreateWithFlags(&e.fork, hipEventDisableTiming));
+        NPW_HIP_CHECK(hipEventCreateWithFlags(&e.join, hipEventDisableTiming));
+    }
+    *out = &e;
+    return NPW_OK;
+}
+}  // namespace npw
+
 extern "C" {
 
 int npw_version(void) { return 100; }
