@@ -520,12 +520,13 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(int n, double*
 }
 
 // ---- fused panel:  rows below the diagonal block  <-  rows * inv(L_jj)^T  -------------------------------------
-// Workgroups 1.. of potrf_panel_kernel each own 64 rows of the block column.  They pull their rows into LDS
+// Workgroups 1.. of potrf_panel_kernel each own PROWS rows of the block column.  They pull their rows into LDS
 // while workgroup 0 is still factoring the diagonal block, spin on a flag until inv(L_jj) is in memory, then
 // multiply from LDS (A operand) and straight from L2 (B operand = inv(L_jj), 128 KiB shared by all of them).
 // Compared with a separate GEMM launch this removes the launch gap, the first global round trip and the
 // LDS staging of a matrix that is used once: ~4 us after the flag instead of ~14 us.
-constexpr int PROWS = 64;
+constexpr int PROWS = 32;  // rows per panel workgroup: 16 output sub-blocks, two per wave (the matrix pipes of one CU
+                           // need 64 cycles per fp64 MFMA, so 64-row strips spent 3.8 us on 576 of them)
 
 constexpr int WPB = JB * (JB + 1);              // one packed 16 x 16 block of inv(L_jj), row stride 17
 constexpr int WP_BLOCKS = NJB * (NJB + 1) / 2;  // 36 blocks on or below the diagonal
@@ -597,18 +598,25 @@ __device__ inline void panel_rows(double* S, double* P, int64_t lda, int rows, c
         }
     }
     __syncthreads();
-    // wave -> one 16-row block and four 16-column blocks, paired so that every wave sums 18 sub-block products
-    const int rb = wave & 3;
-    if (wave < 4) {
-        panel_tile<0>(S, Wp, P, lda, rows, rb, li, lg);
-        panel_tile<7>(S, Wp, P, lda, rows, rb, li, lg);
-        panel_tile<3>(S, Wp, P, lda, rows, rb, li, lg);
-        panel_tile<4>(S, Wp, P, lda, rows, rb, li, lg);
-    } else {
-        panel_tile<1>(S, Wp, P, lda, rows, rb, li, lg);
-        panel_tile<6>(S, Wp, P, lda, rows, rb, li, lg);
-        panel_tile<2>(S, Wp, P, lda, rows, rb, li, lg);
-        panel_tile<5>(S, Wp, P, lda, rows, rb, li, lg);
+    // wave -> one 16-row block and two 16-column blocks (nb, 7 - nb): every wave sums 9 sub-block products
+    const int rb = wave & 1;
+    switch (wave >> 1) {
+        case 0:
+            panel_tile<0>(S, Wp, P, lda, rows, rb, li, lg);
+            panel_tile<7>(S, Wp, P, lda, rows, rb, li, lg);
+            break;
+        case 1:
+            panel_tile<1>(S, Wp, P, lda, rows, rb, li, lg);
+            panel_tile<6>(S, Wp, P, lda, rows, rb, li, lg);
+            break;
+        case 2:
+            panel_tile<2>(S, Wp, P, lda, rows, rb, li, lg);
+            panel_tile<5>(S, Wp, P, lda, rows, rb, li, lg);
+            break;
+        default:
+            panel_tile<3>(S, Wp, P, lda, rows, rb, li, lg);
+            panel_tile<4>(S, Wp, P, lda, rows, rb, li, lg);
+            break;
     }
 }
 
