@@ -181,7 +181,10 @@ def init_process_group(backend=None):
         local = int(os.environ.get("LOCAL_RANK", str(rank)))
         torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
     if not dist.is_initialized():
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        import datetime
+        # a lost peer must end the run with an error, not hang it: collectives / p2p time out
+        limit = datetime.timedelta(seconds=int(os.environ.get("NUMPYWREN_AMD_DIST_TIMEOUT", "900")))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=limit)
     return Comm(rank, world, backend, device_tensors=("nccl" in backend))
 
 
