@@ -266,3 +266,21 @@ def test_qr_factor_triangular_tile_size():
     vo, to, ro = oracle.qr_factor_triangular(x0, x1)
     np.testing.assert_allclose(t, to, atol=1e-10)
     np.testing.assert_allclose(r, ro, atol=1e-10)
+
+
+@pytest.mark.parametrize("log_cond", [6, 12])
+def test_chol_trsm_ill_conditioned(log_cond):
+    """explicit inverses of 128 / 512-wide diagonal blocks must not cost backward stability"""
+    import scipy.linalg as sl
+    rng = np.random.default_rng(log_cond)
+    n = 1024
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    A = (Q * np.logspace(0, -log_cond, n)) @ Q.T
+    A = (A + A.T) / 2
+    L = kernels.chol(A)
+    assert np.linalg.norm(A - L @ L.T) / np.linalg.norm(A) < 5e-15
+    B = rng.standard_normal((300, n))
+    X = kernels.trsm(L, B)
+    assert np.linalg.norm(X @ L.T - B) / (np.linalg.norm(X) * np.linalg.norm(L)) < 1e-15
+    Xr = sl.solve_triangular(np.linalg.cholesky(A), B.T, lower=True).T
+    assert np.linalg.norm(X - Xr) / np.linalg.norm(Xr) < 1e-13 * 10.0 ** log_cond
