@@ -161,7 +161,8 @@ def main():
     def one_step():
         """One factorisation.  On one GPU the step is enqueued and the PREVIOUS one is waited for afterwards
         (program.wait() is where the reference's call sequence waits, too), so the host-side turnaround between two
-        factorisations does not leave the GPU idle; every step is complete before the closing barrier."""
+        factorisations does not leave the GPU idle.  Steps do not overlap on the device (each waits for the previous
+        one's completion events); every step is complete before the closing barrier."""
         program, meta = prebuilt.pop(0)
         for m in meta["outputs"] + meta["intermediates"]:
             m.free()
@@ -169,7 +170,10 @@ def main():
         program.config["executor"]["priority_stream"] = args.priority_stream
         program.start()
         if comm is None:
-            job_runner.lambdapack_run(program, pipeline_width=args.streams, timeout=3600, wait=False)
+            # device-side order: this factorisation starts after the previous one has finished on the GPU (no overlap
+            # of two steps); only the host runs ahead
+            marks = pending[-1][0].completion_marks if pending else None
+            job_runner.lambdapack_run(program, pipeline_width=args.streams, timeout=3600, wait=False, after=marks)
             settle()
             pending.append((program, meta))
         else:

@@ -145,6 +145,14 @@ class LambdaPackExecutor(object):
         mats = self.compiled.matrices
         stream = self.pick_stream(compute)
         device_kernel = getattr(compute, "_npw_device_kernel", False)
+        # A kernel whose workgroups need a whole CU to themselves (the Cholesky panel chain: 150 KiB of LDS each)
+        # starves next to chip-filling GEMMs of other streams -- every launch then waits for ~1 ms workgroups to
+        # retire.  With several streams such a task gets the device to itself: its stream first waits for the other
+        # streams' tails, and they wait for it afterwards.
+        exclusive = len(self.streams) > 1 and getattr(compute, "_npw_needs_whole_cus", False)
+        others = [s for s in self.streams if s is not stream] if exclusive else []
+        for o in others:
+            self.be.wait_event(stream, self.be.record_new(o))
         tiles = [mats[m].get_tile(*idx, stream=stream) for m, idx in task.reads]
         read_bytes = sum(t.nbytes for t in tiles)
         if device_kernel:
@@ -156,6 +164,10 @@ class LambdaPackExecutor(object):
             host = [self.be.to_host(t, stream) for t in tiles]
             args = [host[j] if kind == "tile" else task.consts[j] for kind, j in task.arg_kinds]
             results = compute(*args, **task.kwargs)
+        if others:
+            ev = self.be.record_new(stream)
+            for o in others:
+                self.be.wait_event(o, ev)
         flops_fn = getattr(compute, "flops", None)
         if flops_fn is not None:
             try:
@@ -240,7 +252,7 @@ def check_info_flags(program, be, stream=None):
 
 
 def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, timeout=200, idle_timeout=5,
-                   msg_vis_timeout_jitter=15, compute_threads=1, max_inflight=64, wait=True):
+                   msg_vis_timeout_jitter=15, compute_threads=1, max_inflight=64, wait=True, after=None):
     """Run `program` to completion (or until `timeout` seconds) on the local GPU.
 
     pipeline_width -> number of HIP streams; the SQS visibility / idle / thread arguments of the
@@ -250,7 +262,9 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
     wait=False returns as soon as every task has been enqueued on the device; `program.wait()` -- the next call of
     the reference's sequence start / lambdapack_run / wait / free -- then synchronises, evaluates the deferred
     LinAlgError flags and settles the status.  A caller that factors one matrix after another can enqueue the next
-    program before waiting for the previous one, so the GPU does not idle during the host-side turnaround."""
+    program before waiting for the previous one, so the GPU does not idle during the host-side turnaround.
+    `after` (a list of events, e.g. the `completion_marks` of an earlier run) makes every stream of this run wait for
+    them on the DEVICE first: two runs then never overlap on the GPU although the host has enqueued both."""
     program.incr_up(1)
     t_start = time.time()
     be = get_backend()
@@ -260,6 +274,10 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
     executed, refs, running_times = [], [], []
     inflight = collections.deque()
     program._defer_success = True
+    if after:
+        for sh in list(ex.streams) + ([ex.prio_stream] if ex.prio_stream is not None else []):
+            for ev in after:
+                be.wait_event(sh, ev)
     try:
         while program.program_status() == lp.PS.RUNNING and not program.all_terminators_done():
             node = program.dequeue()
@@ -292,6 +310,7 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
         # whatever a pipelining caller has enqueued behind it)
         used = list(ex.streams) + ([ex.prio_stream] if ex.prio_stream is not None else [])
         marks = [be.record_new(sh) for sh in used] if hasattr(be, "record_new") and hasattr(be, "event_sync") else None
+        program.completion_marks = list(marks) if (marks is not None and not wait) else []
 
         def finish():
             program._finish = None
@@ -301,8 +320,7 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
                     ok = check_info_flags(program, be)
                 else:
                     for ev in marks:
-                        be.event_sync(ev)
-                        be.recycle_event(ev)
+                        be.event_sync(ev)   # (events stay alive: a later run may still be told to wait for them)
                     ok = check_info_flags(program, be, be.flag_stream())
                 program._defer_success = False
                 if ok and program._success_pending and program.program_status() == lp.PS.RUNNING:

@@ -353,6 +353,7 @@ lq_trailing_update.flops = _qr_trailing_flops
 # issues them on its high-priority stream so they overtake queued trailing updates
 for _k in (chol, trsm, qr_factor, lq_factor):
     _k._npw_latency_bound = True
+chol._npw_needs_whole_cus = True   # see job_runner.LambdaPackExecutor.run_task
 
 
 # ------------------------------------------------------------------------------------------------

@@ -65,6 +65,23 @@ class OracleBackend(object):
     def wait_tile(self, tile):
         pass
 
+    # events: the checker runs synchronously, so ordering calls are only recorded
+    def record_new(self, stream=None):
+        self.calls.append(("record", stream))
+        return ("event", stream)
+
+    def wait_event(self, stream, ev):
+        self.calls.append(("wait_event", stream, ev))
+
+    def event_sync(self, ev):
+        pass
+
+    def recycle_event(self, ev):
+        pass
+
+    def flag_stream(self):
+        return self.default_stream
+
     def to_device(self, array, stream=None, dtype=None):
         return HostTile(np.ascontiguousarray(array, dtype=dtype))
 

@@ -51,10 +51,27 @@ def test_cholesky_streams_and_priority(oracle_backend):
     program, meta = alg_wrappers.cholesky(X)
     program.config["executor"]["priority_stream"] = True
     run(program, pipeline_width=3)
-    prio = {s for k, s in oracle_backend.calls if k in ("chol", "trsm")}
-    bulk = {s for k, s in oracle_backend.calls if k == "syrk"}
+    prio = {c[1] for c in oracle_backend.calls if c[0] in ("chol", "trsm")}
+    bulk = {c[1] for c in oracle_backend.calls if c[0] == "syrk"}
     assert prio == {oracle_backend.priority_stream}            # panel kernels on the high-priority stream
     assert len(bulk) == 3 and oracle_backend.priority_stream not in bulk
+
+
+def test_chol_gets_the_device_to_itself_with_several_streams(oracle_backend):
+    """the Cholesky panel chain needs whole CUs: its stream waits for the other streams' tails and they wait for it"""
+    A = ALG["cholesky_32_8/A"]
+    X = BigMatrix("chol_excl", shape=A.shape, shard_sizes=(8, 8))
+    shard_matrix(X, A)
+    program, meta = alg_wrappers.cholesky(X)
+    run(program, pipeline_width=3)
+    calls = oracle_backend.calls
+    for i, c in enumerate(calls):
+        if c[0] != "chol":
+            continue
+        s = c[1]
+        before = [x for x in calls[max(0, i - 8):i] if x[0] == "wait_event" and x[1] == s]
+        after = [x for x in calls[i + 1:i + 8] if x[0] == "wait_event" and x[2] == ("event", s)]
+        assert len(before) >= 2 and len(after) == 2, (before, after)
 
 
 def test_cholesky_not_positive_definite(oracle_backend):
