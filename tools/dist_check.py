@@ -30,7 +30,7 @@ def _owned_scatter(M, A, comm, rank):
 
 def _run(program, comm):
     program.start()
-    res = dist.lambdapack_run_distributed(program, comm)
+    res = dist.lambdapack_run_distributed(program, comm, pipeline_width=int(os.environ.get("DIST_CHECK_STREAMS", "3")))
     return program.program_status() == lp.PS.SUCCESS, res
 
 
