@@ -313,7 +313,10 @@ def test_two_factorisations_in_flight(hbm_store):
         shard_matrix(X, A)
         program, meta = alg_wrappers.cholesky(X)
         program.start()
-        job_runner.lambdapack_run(program, wait=False)
+        # the second run is ordered behind the first on the device (after=), both are enqueued before either is settled
+        marks = progs[-1][0].completion_marks if progs else None
+        job_runner.lambdapack_run(program, wait=False, after=marks, pipeline_width=1 + t)
+        assert program.completion_marks
         progs.append((program, meta, A))
     for program, meta, A in progs:
         program.wait()
