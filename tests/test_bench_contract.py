@@ -1,0 +1,47 @@
+"""bench.py's one-line contract (driver-facing): field names, types and the two extra objects.  The GPU test runs a
+reduced workload (small tiles) through the real code path; the CPU test checks the committed round-1 line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric": str, "value": (int, float), "unit": str, "n_gpus": int, "steps": int, "warmup": int,
+            "ms_per_step": (int, float), "higher_is_better": bool, "scaling": str, "dtype": str, "data": str,
+            "config": dict}
+
+
+def _check_line(line, n_gpus=1):
+    for k, t in REQUIRED.items():
+        assert k in line and isinstance(line[k], t), k
+    assert "vs_baseline" in line and line["vs_baseline"] is None      # BASELINE.md holds no published number
+    assert line["n_gpus"] == n_gpus and line["higher_is_better"] is True and line["scaling"] == "weak"
+    assert line["dtype"] == "f64" and line["data"] == "synthetic" and "workload" in line["config"]
+    assert line["value"] > 0 and line["ms_per_step"] > 0
+
+
+def test_committed_round1_line():
+    with open(os.path.join(ROOT, "profiles", "r01_bench_line.json")) as f:
+        line = json.loads(f.read().strip().splitlines()[-1])
+    _check_line(line)
+    roof, cpu = line["roofline"], line["cpu_baseline"]
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 78.6
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and roof["traffic"] > 0
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
+    assert abs(line["value"] - line["steps"] * (line["config"]["n"] ** 3 / 3) / (line["ms_per_step"] * 1e-3 * line["steps"]) / 1e12) < 0.05
+
+
+@pytest.mark.gpu
+def test_bench_runs_and_prints_one_json_line():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--tile", "512",
+           "--tiles", "4", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    _check_line(line)
+    assert line["config"]["residual_tile_1_1"] < 1e-13
+    assert line["roofline"]["traffic"] is None            # PMC figure only applies to the 4096^2 tile
