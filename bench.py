@@ -157,6 +157,7 @@ def main():
             program.wait()
             if program.program_status() != lp.PS.SUCCESS:
                 raise SystemExit(f"cholesky failed: {program.exceptions}")
+            program.free()
 
     def one_step():
         """One factorisation.  On one GPU the step is enqueued and the PREVIOUS one is waited for afterwards

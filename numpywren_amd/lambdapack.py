@@ -447,6 +447,12 @@ class LambdaPackProgram(object):
         with self._lock:
             self._ready = []
             self._edges = {}
+        marks, self.completion_marks = getattr(self, "completion_marks", None), []
+        if marks:   # events of a lambdapack_run(wait=False): nobody may be told to wait for them after free()
+            from .device import get_backend
+            be = get_backend()
+            for ev in marks:
+                be.recycle_event(ev)
 
     # ---- counters (reference lambdapack.py:683-752; Redis keys become dict entries) ----
     def _incr(self, name, amount=1):
