@@ -19,6 +19,10 @@ DEFAULTS = {
     "store": {
         "tier": "hbm",           # "hbm" (device memory) or "host" (pinned/pageable host memory)
         "device_pool": True,
+        # Byte budget for tiles stored in HBM (int or "200G"); beyond it the least-recently-used tiles move to pinned
+        # host DRAM and come back on their next read (residency.py).  None: no budget -- tiles are only pushed out
+        # when a device allocation fails.  $NUMPYWREN_AMD_HBM_BUDGET overrides.
+        "hbm_budget_bytes": None,
     },
     "runtime": {"bucket": "hbm"},
 }

@@ -71,6 +71,62 @@ class DeviceBuffer(object):
                 pass
 
 
+class PinnedBuffer(object):
+    """Page-locked host memory from the backend's pinned pool (hipHostMalloc): the target of asynchronous D2H
+    copies when a tile is spilled out of HBM.  `streams` are the copy streams that touched the memory: the buffer is
+    reused only after they have passed the release point."""
+    __slots__ = ("ptr", "nbytes", "_backend", "streams", "__weakref__")
+
+    def __init__(self, backend, ptr, nbytes):
+        self.ptr = ptr
+        self.nbytes = nbytes
+        self._backend = backend
+        self.streams = set()
+
+    def __del__(self):
+        be = self._backend
+        if be is not None and self.ptr:
+            try:
+                be._release_pinned(self.ptr, self.nbytes, self.streams)
+            except Exception:
+                pass
+            self.ptr = 0
+
+
+class SpilledTile(object):
+    """A tile that left HBM for pinned host memory (the store's host-DRAM tier).  `ready` is the event that marks
+    the end of the D2H copy; the bytes must not be read on the host before it has completed."""
+    __slots__ = ("buf", "shape", "dtype", "ready", "__weakref__")
+
+    def __init__(self, buf, shape, dtype, ready=None):
+        self.buf = buf
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.ready = ready
+
+    @property
+    def nbytes(self):
+        return int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+
+    def __repr__(self):
+        return f"SpilledTile(shape={self.shape}, dtype={self.dtype})"
+
+
+class _Ready(tuple):
+    """(event, stream) of a tile's producer; the event goes back to the backend's pool with the last holder."""
+
+    def __new__(cls, ev, sh, backend):
+        self = tuple.__new__(cls, (ev, sh))
+        self.backend = backend
+        return self
+
+    def __del__(self):
+        try:
+            self.backend.recycle_event(self[0])
+        except Exception:
+            pass
+
+
 class DeviceTile(object):
     """One tile resident in HBM: a C-contiguous array of `shape`/`dtype` inside a DeviceBuffer."""
     __slots__ = ("buf", "shape", "dtype", "ready", "zero_flag", "shared", "__weakref__")
@@ -165,6 +221,13 @@ class HipBackend(object):
             for i in range(max(1, num_streams)):
                 self.bulk_streams.append(self.create_masked_stream(self.reserve_cus, name=f"bulk{i}"))
         self._zero_tiles = {}
+        self._spill_streams = None
+        self._pinned_free = {}   # nbytes -> [(ptr, event or None)]
+        self.pinned_bytes = 0
+        self.pinned_pooled_bytes = 0
+        self.spilled_bytes_total = 0
+        self.restored_bytes_total = 0
+        self.oom_handlers = []   # callables(nbytes) -> bytes they made reclaimable (the store's spill tier)
         self._tls = threading.local()
         self.kernel_timers = None  # name -> [(start_event, stop_event)] when enabled (bench.py roofline)
 
@@ -322,10 +385,17 @@ class HipBackend(object):
         p = ctypes.c_void_p(0)
         rc = self.lib.npw_malloc(ctypes.byref(p), nbytes)
         if rc != 0:
-            # out of memory: give everything cached back to the driver and retry once
+            # out of memory: give everything cached back to the driver and retry; then let the store push
+            # least-recently-used tiles out to pinned host memory and retry once more
             self.synchronize()
             self.trim()
-            _ffi.check(self.lib.npw_malloc(ctypes.byref(p), nbytes), f"npw_malloc({nbytes})")
+            rc = self.lib.npw_malloc(ctypes.byref(p), nbytes)
+            if rc != 0 and self.oom_handlers:
+                if sum(h(nbytes) for h in list(self.oom_handlers)) > 0:
+                    self.synchronize()
+                    self.trim()
+                    rc = self.lib.npw_malloc(ctypes.byref(p), nbytes)
+            _ffi.check(rc, f"npw_malloc({nbytes})")
         with self._lock:
             self.allocated_bytes += nbytes
             self.peak_bytes = max(self.peak_bytes, self.allocated_bytes)
@@ -393,8 +463,9 @@ class HipBackend(object):
     def _produced(self, stream, *tiles):
         sh = self._sh(stream)
         ev = self.record_new(sh)
+        ready = _Ready(ev, sh, self)
         for t in tiles:
-            t.ready = (ev, sh)
+            t.ready = ready
             t.buf.streams.add(sh)
             t.zero_flag = None
         return ev
@@ -424,6 +495,97 @@ class HipBackend(object):
         if tile.nbytes:
             _ffi.check(self.lib.npw_memcpy_d2h_async(out.ctypes.data, tile.ptr, tile.nbytes, sh), "d2h")
         self.stream_sync(sh)
+        return out
+
+    # ------------------------------------------------------------------ host-DRAM tier (pinned, asynchronous)
+    def spill_stream(self, inbound=False):
+        """The streams the HBM <-> pinned-host copies of the spill tier run on, beside the compute streams: one per
+        direction, so that evictions and restores use both directions of the host link at once."""
+        with self._lock:
+            if self._spill_streams is None:
+                self._spill_streams = (self.create_stream(name="spill_out"), self.create_stream(name="spill_in"))
+            return self._spill_streams[1 if inbound else 0]
+
+    def alloc_pinned(self, nbytes):
+        nbytes = max(4096, _round_up(int(nbytes), 4096))
+        ptr = None
+        with self._lock:
+            lst = self._pinned_free.get(nbytes)
+            if lst:
+                ptr, evs = lst.pop()
+                self.pinned_pooled_bytes -= nbytes
+        if ptr is not None:
+            for ev in evs:  # a copy out of this buffer may still be in flight
+                self.event_sync(ev)
+                self.recycle_event(ev)
+            return PinnedBuffer(self, ptr, nbytes)
+        p = ctypes.c_void_p(0)
+        _ffi.check(self.lib.npw_host_alloc(ctypes.byref(p), nbytes), f"npw_host_alloc({nbytes})")
+        with self._lock:
+            self.pinned_bytes += nbytes
+        return PinnedBuffer(self, p.value, nbytes)
+
+    def _release_pinned(self, ptr, nbytes, streams):
+        evs = [self.record_new(sh) for sh in streams]
+        with self._lock:
+            self._pinned_free.setdefault(nbytes, []).append((ptr, evs))
+            self.pinned_pooled_bytes += nbytes
+
+    def trim_pinned(self):
+        """Give the unused pinned buffers back to the OS."""
+        with self._lock:
+            free, self._pinned_free = self._pinned_free, {}
+            self.pinned_pooled_bytes = 0
+        for nbytes, lst in free.items():
+            for ptr, evs in lst:
+                for ev in evs:
+                    self.event_sync(ev)
+                    self.recycle_event(ev)
+                self.lib.npw_host_free(ptr)
+                with self._lock:
+                    self.pinned_bytes -= nbytes
+
+    def spill_to_host(self, tile):
+        """Start an asynchronous copy of `tile` into pinned host memory (after its producer) and return the
+        SpilledTile that stands for it.  The device buffer goes back to the pool once every holder has dropped
+        the tile and the copy has left the spill stream."""
+        kept = tile.buf.aux.get("host_copy") if isinstance(tile.buf.aux, dict) else None
+        if kept is not None and kept.nbytes == tile.nbytes and kept.dtype == tile.dtype:
+            return kept if kept.shape == tile.shape else SpilledTile(kept.buf, tile.shape, tile.dtype, kept.ready)
+        sp = self.spill_stream()
+        self._use(sp, tile)
+        buf = self.alloc_pinned(tile.nbytes)
+        if tile.nbytes:
+            _ffi.check(self.lib.npw_memcpy_d2h_async(buf.ptr, tile.ptr, tile.nbytes, sp.handle), "spill d2h")
+        with self._lock:
+            self.spilled_bytes_total += tile.nbytes
+        buf.streams.add(sp.handle)
+        return SpilledTile(buf, tile.shape, tile.dtype, self.record_new(sp))
+
+    def restore_from_host(self, spilled):
+        """A new DeviceTile with the contents of `spilled`, copied on the inbound spill stream behind the D2H that
+        filled the host buffer; consumers wait for the tile's `ready` event as for any producer.  The tile remembers
+        its host copy (`buf.aux["host_copy"]`): stored tiles are immutable, so pushing it out again costs no copy."""
+        sp = self.spill_stream(inbound=True)
+        t = self.empty(spilled.shape, spilled.dtype)
+        if spilled.ready is not None:
+            self.wait_event(sp, spilled.ready)
+        if t.nbytes:
+            _ffi.check(self.lib.npw_memcpy_h2d_async(t.ptr, spilled.buf.ptr, t.nbytes, sp.handle), "restore h2d")
+        self._produced(sp, t)
+        spilled.buf.streams.add(sp.handle)
+        t.buf.aux = {"host_copy": spilled}
+        with self._lock:
+            self.restored_bytes_total += t.nbytes
+        return t
+
+    def spilled_to_numpy(self, spilled):
+        """Host copy of a spilled tile without a round trip through HBM."""
+        if spilled.ready is not None:
+            self.event_sync(spilled.ready)
+        out = np.empty(spilled.shape, dtype=spilled.dtype)
+        if out.nbytes:
+            ctypes.memmove(out.ctypes.data, spilled.buf.ptr, out.nbytes)
         return out
 
     def copy(self, tile, stream=None):

@@ -26,7 +26,8 @@ import numpy as np
 
 from . import config as _config
 from . import utils
-from .device import DeviceTile, get_backend
+from .device import DeviceTile, SpilledTile, get_backend
+from .residency import Residency
 
 DEFAULT_BUCKET = "hbm"
 DEFAULT_REGION = "local"
@@ -47,8 +48,16 @@ class _ObjectTable(object):
                 d = self.objects[(bucket, key_base)] = {}
             return d
 
+    def clear(self):
+        """Forget every tile and header (tests)."""
+        with self.lock:
+            self.objects.clear()
+            self.headers.clear()
+            RESIDENCY.reset()
+
 
 OBJECTS = _ObjectTable()
+RESIDENCY = Residency(OBJECTS)   # which stored tiles are in HBM, which in pinned host DRAM (residency.py)
 
 
 def _store_tier():
@@ -254,6 +263,8 @@ class BigMatrix(object):
             X_block = np.array(self._call_parent(block_idx))
         elif isinstance(obj, DeviceTile):
             X_block = get_backend().to_host(obj)
+        elif isinstance(obj, SpilledTile):
+            X_block = get_backend().spilled_to_numpy(obj)   # straight from pinned memory, no trip through HBM
         else:
             X_block = np.array(obj)
         if self.autosqueeze:
@@ -283,6 +294,15 @@ class BigMatrix(object):
                 tile = be.to_device(np.asarray(self._call_parent(block_idx)), stream)
         elif isinstance(obj, DeviceTile):
             tile = obj
+            with OBJECTS.lock:
+                RESIDENCY.touch((self.bucket, self.key_base, key))
+        elif isinstance(obj, SpilledTile):
+            with OBJECTS.lock:
+                cur, _ = self._raw(block_idx)   # somebody else may have restored it meanwhile
+                if isinstance(cur, SpilledTile):
+                    tile = RESIDENCY.restore((self.bucket, self.key_base, key), cur, be)
+                else:
+                    tile = cur if isinstance(cur, DeviceTile) else be.to_device(cur, stream)
         else:
             tile = be.to_device(obj, stream)
         if self.autosqueeze:
@@ -316,9 +336,17 @@ class BigMatrix(object):
             obj = np.array(block).reshape(shape)
         else:
             obj = get_backend().to_device(block.reshape(shape))
+        self._store(key, obj)
+        return None
+
+    def _store(self, key, obj):
         with OBJECTS.lock:
             self._tiles()[key] = obj
-        return None
+            tkey = (self.bucket, self.key_base, key)
+            RESIDENCY.note_put(tkey, obj)
+            if isinstance(obj, DeviceTile):
+                RESIDENCY._hook(get_backend())
+                RESIDENCY.enforce(protect=(tkey,))
 
     async def put_block_async(self, block, loop=None, *block_idx, no_overwrite=False):
         if no_overwrite and self.tile_exists(*block_idx):
@@ -335,8 +363,7 @@ class BigMatrix(object):
             obj = get_backend().to_host(tile)
         else:
             obj = tile
-        with OBJECTS.lock:
-            self._tiles()[key] = obj
+        self._store(key, obj)
         return None
 
     def delete_block(self, *block_idx):
@@ -345,6 +372,7 @@ class BigMatrix(object):
             d = self._tiles(False)
             if d is not None:
                 d.pop(key, None)
+            RESIDENCY.note_delete((self.bucket, self.key_base, key))
         return None
 
     async def delete_block_async(self, loop=None, *block_idx):
@@ -355,6 +383,8 @@ class BigMatrix(object):
         with OBJECTS.lock:
             d = self._tiles(False)
             if d is not None:
+                for key in d:
+                    RESIDENCY.note_delete((self.bucket, self.key_base, key))
                 d.clear()
         return 0
 

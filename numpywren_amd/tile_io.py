@@ -54,7 +54,9 @@ def _object_path(root, bucket, key):
 def _host_array(tile):
     if isinstance(tile, np.ndarray):
         return tile
-    from .device import get_backend
+    from .device import SpilledTile, get_backend
+    if isinstance(tile, SpilledTile):
+        return get_backend().spilled_to_numpy(tile)
     return get_backend().to_host(tile)
 
 

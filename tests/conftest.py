@@ -37,11 +37,9 @@ def host_store(monkeypatch):
     """Keep BigMatrix tiles in host memory (the spill tier) so storage logic runs without a GPU."""
     monkeypatch.setenv("NUMPYWREN_AMD_STORE", "host")
     from numpywren_amd import matrix
-    matrix.OBJECTS.objects.clear()
-    matrix.OBJECTS.headers.clear()
+    matrix.OBJECTS.clear()
     yield
-    matrix.OBJECTS.objects.clear()
-    matrix.OBJECTS.headers.clear()
+    matrix.OBJECTS.clear()
 
 
 @pytest.fixture
@@ -52,20 +50,16 @@ def oracle_backend(monkeypatch):
     from oracle_backend import OracleBackend
     be = OracleBackend()
     device.set_backend(be)
-    matrix.OBJECTS.objects.clear()
-    matrix.OBJECTS.headers.clear()
+    matrix.OBJECTS.clear()
     yield be
     device.set_backend(None)
-    matrix.OBJECTS.objects.clear()
-    matrix.OBJECTS.headers.clear()
+    matrix.OBJECTS.clear()
 
 
 @pytest.fixture
 def hbm_store(monkeypatch):
     monkeypatch.setenv("NUMPYWREN_AMD_STORE", "hbm")
     from numpywren_amd import matrix
-    matrix.OBJECTS.objects.clear()
-    matrix.OBJECTS.headers.clear()
+    matrix.OBJECTS.clear()
     yield
-    matrix.OBJECTS.objects.clear()
-    matrix.OBJECTS.headers.clear()
+    matrix.OBJECTS.clear()

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import npw_oracle as oracle  # noqa: E402
 
-from numpywren_amd.device import DeviceTile, Stream  # noqa: E402
+from numpywren_amd.device import DeviceTile, SpilledTile, Stream  # noqa: E402
 
 
 class _Buf(object):
@@ -38,6 +38,11 @@ class HostTile(DeviceTile):
         return t
 
 
+class _Bytes(object):
+    def __init__(self, array):
+        self.array = array
+
+
 class _Flag(object):
     def __init__(self, v):
         self.value = int(v)
@@ -51,6 +56,7 @@ class OracleBackend(object):
         self.priority_stream = Stream(99, True, "prio")
         self.device = 0
         self.calls = []
+        self.oom_handlers = []
 
     # plumbing -------------------------------------------------------------------------------
     def bind_thread(self):
@@ -98,6 +104,18 @@ class OracleBackend(object):
 
     def copy(self, tile, stream=None):
         return HostTile(tile.array)
+
+    # host-DRAM tier: "pinned memory" is an ndarray here, the copies are synchronous
+    def spill_to_host(self, tile):
+        self.calls.append(("spill", tile.shape))
+        return SpilledTile(_Bytes(np.array(tile.array)), tile.shape, tile.dtype)
+
+    def restore_from_host(self, spilled):
+        self.calls.append(("restore", spilled.shape))
+        return HostTile(spilled.buf.array.reshape(spilled.shape))
+
+    def spilled_to_numpy(self, spilled):
+        return np.array(spilled.buf.array).reshape(spilled.shape)
 
     def read_flag(self, flag, stream=None):
         return flag.value

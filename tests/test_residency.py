@@ -1,0 +1,241 @@
+"""The store's host-DRAM tier (numpywren_amd/residency.py): LRU policy and bookkeeping on the CPU with the checker
+backend, the pinned asynchronous copies and the out-of-memory path on the GPU."""
+import numpy as np
+import pytest
+
+from numpywren_amd import matrix, residency
+from numpywren_amd.device import DeviceTile, SpilledTile
+from numpywren_amd.matrix import BigMatrix
+
+TILE = 16 * 16 * 8
+
+
+def _mat(key, nb=4, b=16):
+    m = BigMatrix(key, shape=(nb * b, nb * b), shard_sizes=(b, b), write_header=True)
+    rng = np.random.default_rng(5)
+    ref = {}
+    for i in range(nb):
+        for j in range(nb):
+            ref[i, j] = rng.standard_normal((b, b))
+            m.put_block(ref[i, j], i, j)
+    return m, ref
+
+
+def _kinds(m):
+    return {matrix.block_key_to_block(k): type(v) for k, v in m._tiles(False).items()}
+
+
+def test_parse_bytes():
+    assert residency.parse_bytes(None) is None
+    assert residency.parse_bytes("none") is None
+    assert residency.parse_bytes(1234) == 1234
+    assert residency.parse_bytes("1234") == 1234
+    assert residency.parse_bytes("2k") == 2048
+    assert residency.parse_bytes("200G") == 200 << 30
+    assert residency.parse_bytes("1.5 GiB") == 3 << 29
+    assert residency.parse_bytes("512MB") == 512 << 20
+    with pytest.raises(ValueError):
+        residency.parse_bytes("lots")
+
+
+def test_no_budget_keeps_everything_resident(oracle_backend):
+    m, _ = _mat("res_nobudget")
+    st = matrix.RESIDENCY.stats()
+    assert st["resident_tiles"] == 16 and st["resident_bytes"] == 16 * TILE and st["evictions"] == 0
+    m.free()
+    assert matrix.RESIDENCY.stats()["resident_bytes"] == 0
+
+
+def test_budget_evicts_least_recently_used(oracle_backend):
+    matrix.RESIDENCY.set_budget(6 * TILE)
+    m, ref = _mat("res_lru")
+    st = matrix.RESIDENCY.stats()
+    assert st["resident_bytes"] == 6 * TILE and st["evictions"] == 10
+    kinds = _kinds(m)
+    spilled = sorted(k for k, t in kinds.items() if t is SpilledTile)
+    assert len(spilled) == 10
+    # the ten oldest puts went: rows 0, 1 and (2,0), (2,1)
+    assert spilled == sorted(m.blocks[:10])
+    # reads return the bytes that left, spilled or not; get_block of a spilled tile does not promote it
+    for (i, j), a in ref.items():
+        assert np.array_equal(m.get_block(i, j), a)
+    assert matrix.RESIDENCY.stats()["restores"] == 0
+    # get_tile promotes: the tile is resident again and the least recently used resident tile makes room
+    t = m.get_tile(0, 0)
+    assert isinstance(t, DeviceTile) and np.array_equal(oracle_backend.to_host(t), ref[0, 0])
+    st = matrix.RESIDENCY.stats()
+    assert st["restores"] == 1 and st["resident_bytes"] == 6 * TILE
+    kinds = _kinds(m)
+    assert kinds[m.blocks[0]] is not SpilledTile
+    assert kinds[m.blocks[10]] is SpilledTile      # (2,2) was the oldest resident one
+    # touching protects: read (2,3), then promote another tile -> (3,0) goes, not (2,3)
+    m.get_tile(2, 3)
+    m.get_tile(0, 1)
+    kinds = _kinds(m)
+    assert kinds[m.blocks[11]] is not SpilledTile and kinds[m.blocks[12]] is SpilledTile
+    assert np.array_equal(m.numpy(), np.block([[ref[i, j] for j in range(4)] for i in range(4)]))
+
+
+def test_shared_buffers_move_together_and_deletes_are_accounted(oracle_backend):
+    be = oracle_backend
+    m = BigMatrix("res_shared", shape=(64, 16), shard_sizes=(16, 16), write_header=True)
+    a = np.arange(256.0).reshape(16, 16)
+    t = be.to_device(a)
+    m.put_tile(t, 0, 0)
+    m.put_tile(t, 1, 0)          # same buffer under two keys (what kernels.identity produces)
+    assert matrix.RESIDENCY.stats()["resident_bytes"] == TILE
+    m.put_block(a + 1, 2, 0)
+    assert matrix.RESIDENCY.stats()["resident_bytes"] == 2 * TILE
+    matrix.RESIDENCY.set_budget(TILE)
+    kinds = _kinds(m)
+    assert kinds[m.blocks[0]] is SpilledTile and kinds[m.blocks[1]] is SpilledTile
+    assert matrix.RESIDENCY.stats()["evictions"] == 1     # one copy for the shared buffer
+    assert np.array_equal(m.get_block(1, 0), a) and np.array_equal(m.get_block(0, 0), a)
+    m.delete_block(2, 0)
+    assert matrix.RESIDENCY.stats()["resident_bytes"] == 0
+    m.put_block(a + 2, 3, 0)
+    m.put_block(a + 3, 3, 0)     # overwrite: the old object stops counting
+    assert matrix.RESIDENCY.stats()["resident_bytes"] == TILE
+    # constant zero tiles are shared read-only objects of the backend: never counted, never evicted
+    z = be.shared_zeros((16, 16))
+    m.put_tile(z, 2, 0)
+    assert matrix.RESIDENCY.stats()["resident_bytes"] == TILE and _kinds(m)[m.blocks[2]] is not SpilledTile
+
+
+def test_reclaim_is_the_allocators_out_of_memory_handler(oracle_backend):
+    m, ref = _mat("res_oom")
+    assert matrix.RESIDENCY.reclaim in oracle_backend.oom_handlers
+    freed = oracle_backend.oom_handlers[0](3 * TILE)
+    assert freed == 3 * TILE and matrix.RESIDENCY.stats()["resident_bytes"] == 13 * TILE
+    assert sorted(k for k, t in _kinds(m).items() if t is SpilledTile) == sorted(m.blocks[:3])
+    for (i, j), a in ref.items():
+        assert np.array_equal(oracle_backend.to_host(m.get_tile(i, j)), a)
+
+
+def test_cholesky_under_a_tight_budget(oracle_backend):
+    """The executor never sees the tier: a program runs to the same result with almost nothing resident."""
+    from numpywren_amd import alg_wrappers, job_runner
+    from numpywren_amd import lambdapack as lp
+    rng = np.random.default_rng(3)
+    n, b = 64, 16
+    x = rng.standard_normal((n, n))
+    a = x @ x.T + n * np.eye(n)
+    A = BigMatrix("res_chol_in", shape=(n, n), shard_sizes=(b, b), write_header=True)
+    matrix.RESIDENCY.set_budget(3 * TILE)
+    for i in range(4):
+        for j in range(4):
+            A.put_block(a[i * b:(i + 1) * b, j * b:(j + 1) * b], i, j)
+    program, meta = alg_wrappers.cholesky(A)
+    program.start()
+    job_runner.lambdapack_run(program)
+    program.wait()
+    assert program.program_status() == lp.PS.SUCCESS
+    L = meta["outputs"][0].numpy()
+    assert np.allclose(L, np.linalg.cholesky(a))
+    st = matrix.RESIDENCY.stats()
+    assert st["resident_bytes"] <= 3 * TILE and st["evictions"] > 10 and st["restores"] > 5
+    program.free()
+
+
+# ------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_spill_and_restore_are_bit_exact_and_asynchronous(hbm_store):
+    from numpywren_amd.device import get_backend
+    be = get_backend()
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((1024, 1024))
+    t = be.to_device(a)
+    prod = be.gemm(t, t)                      # spilling must wait for the producer on another stream
+    sp = be.spill_to_host(prod)
+    assert isinstance(sp, SpilledTile) and sp.nbytes == prod.nbytes
+    back = be.restore_from_host(sp)
+    want = be.to_host(prod)
+    assert np.array_equal(be.to_host(back), want)
+    assert np.array_equal(be.spilled_to_numpy(sp), want)
+    # pinned buffers are pooled
+    before = be.pinned_bytes
+    del sp, back
+    sp2 = be.spill_to_host(prod)
+    assert be.pinned_bytes == before
+    assert np.array_equal(be.spilled_to_numpy(sp2), want)
+    del sp2
+    be.trim_pinned()
+    assert be.pinned_bytes == 0
+
+
+@pytest.mark.gpu
+def test_budgeted_cholesky_matches_unbudgeted_bitwise(hbm_store):
+    """Same program, same kernels, same order: a budget of a few tiles changes where tiles wait, not one bit of L."""
+    from numpywren_amd import alg_wrappers, job_runner
+    from numpywren_amd import lambdapack as lp
+    from numpywren_amd.device import get_backend
+    be = get_backend()
+    n, b = 1536, 256
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((n, n))
+    a = x @ x.T + n * np.eye(n)
+
+    def run(key, budget):
+        matrix.RESIDENCY.set_budget(budget)
+        A = BigMatrix(key, shape=(n, n), shard_sizes=(b, b), write_header=True)
+        for i in range(n // b):
+            for j in range(n // b):
+                A.put_block(a[i * b:(i + 1) * b, j * b:(j + 1) * b], i, j)
+        program, meta = alg_wrappers.cholesky(A)
+        program.start()
+        job_runner.lambdapack_run(program)
+        program.wait()
+        assert program.program_status() == lp.PS.SUCCESS
+        L = meta["outputs"][0].numpy()
+        st = matrix.RESIDENCY.stats()
+        program.free()
+        A.free()
+        return L, st
+
+    L0, st0 = run("res_gpu_free", None)
+    assert st0["evictions"] == 0
+    L1, st1 = run("res_gpu_tight", 8 * b * b * 8)
+    assert st1["evictions"] > 20 and st1["restores"] > 20
+    assert np.array_equal(L0, L1)
+    assert np.linalg.norm(L1 @ L1.T - a) / np.linalg.norm(a) < 1e-13
+    matrix.RESIDENCY.set_budget(None)
+    be.trim_pinned()
+
+
+@pytest.mark.gpu
+def test_allocation_failure_pushes_tiles_out(hbm_store, monkeypatch):
+    """Drive the out-of-memory path without filling 288 GB: the first npw_malloc of a fresh size is made to fail."""
+    import ctypes
+    from numpywren_amd.device import get_backend
+    be = get_backend()
+    m = BigMatrix("res_gpu_oom", shape=(1024, 256), shard_sizes=(256, 256), write_header=True)
+    rng = np.random.default_rng(1)
+    ref = [rng.standard_normal((256, 256)) for _ in range(4)]
+    for i, r in enumerate(ref):
+        m.put_block(r, i, 0)
+    be.synchronize()
+    real = be.lib.npw_malloc
+    fails = {"left": 2}
+
+    class Lib(object):
+        def __getattr__(self, name):
+            return getattr(be_lib, name)
+
+        def npw_malloc(self, p, nbytes):
+            if nbytes == 3 * 256 * 256 * 8 + 256 and fails["left"] > 0:
+                fails["left"] -= 1
+                return -2
+            return real(p, nbytes)
+
+    be_lib = be.lib
+    monkeypatch.setattr(be, "lib", Lib())
+    t = be.empty((3 * 256 * 256 + 32,), np.float64)   # fails twice -> trim, then reclaim, then succeeds
+    assert t.nbytes == 3 * 256 * 256 * 8 + 256 and fails["left"] == 0
+    monkeypatch.undo()
+    st = matrix.RESIDENCY.stats()
+    assert st["evictions"] == 4 and st["resident_bytes"] == 0      # 4 tiles of 512 KiB < the 1.5 MiB asked for
+    for i, r in enumerate(ref):
+        assert np.array_equal(be.to_host(m.get_tile(i, 0)), r)
+    assert matrix.RESIDENCY.stats()["restores"] == 4
+    m.free()
+    be.trim_pinned()

@@ -4,6 +4,7 @@
     python tools/bench_aux.py gemm32  [--n 16384]       # configs[4] family: fp32 GEMM program, 4096^2 tiles
     python tools/bench_aux.py tsqr    [--leaves 16]     # configs[3] family: (leaves*4096) x 4096 fp64 TSQR
     python tools/bench_aux.py chol    [--tiles 8]       # the Cholesky DAG on a larger tile grid
+    python tools/bench_aux.py spill   [--tiles 4] [--budget-tiles 6]   # host-DRAM tier: copy rates, budgeted Cholesky
 
 Each prints one JSON line.  Inputs are generated on the device and resident in HBM before timing;
 programs are compiled before the clock starts (like bench.py)."""
@@ -56,7 +57,8 @@ def timed(build, steps, warmup):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["gemm32", "tsqr", "chol"])
+    ap.add_argument("what", choices=["gemm32", "tsqr", "chol", "spill"])
+    ap.add_argument("--budget-tiles", type=int, default=6)
     ap.add_argument("--n", type=int, default=16384)
     ap.add_argument("--leaves", type=int, default=16)
     ap.add_argument("--tiles", type=int, default=8)
@@ -106,6 +108,65 @@ def main():
         print(json.dumps({"what": f"{m} x {b} fp64 TSQR (alg_wrappers.tsqr), {a.leaves} leaves, {2 * a.leaves - 1} tasks",
                           "ms": round(dt * 1e3, 2), "TFLOP/s(2mn^2-2n^3/3)": round(flops / dt / 1e12, 3),
                           "rel_err_RtR": float(err)}))
+    elif a.what == "spill":
+        from numpywren_amd import matrix
+        # 1. the copies themselves: one tile out to pinned memory and back, on the spill stream
+        t = be.fill_random((b, b), 3)
+        be.synchronize()
+        out, back, both = [], [], []
+        t2nd = be.fill_random((b, b), 4)
+        for _ in range(4):
+            t0 = time.time()
+            sp = be.spill_to_host(t)
+            be.stream_sync(be.spill_stream())
+            t1 = time.time()
+            r = be.restore_from_host(sp)
+            be.stream_sync(be.spill_stream(inbound=True))
+            t2 = time.time()
+            # both directions at once: one tile leaves while another comes back
+            sp2 = be.spill_to_host(t2nd)
+            r2 = be.restore_from_host(sp)
+            be.stream_sync(be.spill_stream())
+            be.stream_sync(be.spill_stream(inbound=True))
+            t3 = time.time()
+            out.append(t.nbytes / (t1 - t0) / 1e9)
+            back.append(t.nbytes / (t2 - t1) / 1e9)
+            both.append(2 * t.nbytes / (t3 - t2) / 1e9)
+            del sp, r, sp2, r2
+        # 2. the 16384^2-style Cholesky with all tiles resident and with a budget of a few tiles
+        nt = a.tiles
+        n = nt * b
+        import bench
+
+        res = {}
+        for label, budget in (("resident", None), ("budget", a.budget_tiles * b * b * 8)):
+            matrix.RESIDENCY.set_budget(budget)
+            A = bench.build_input(be, nt, b, "aux_spill_" + label)
+            times = []
+            for rep in range(a.steps + a.warmup):
+                program, meta = alg_wrappers.cholesky(A)
+                program.program.tasks
+                be.synchronize()
+                t0 = time.time()
+                run(program, reclaim=True)
+                be.synchronize()
+                times.append(time.time() - t0)
+                last = meta
+                if rep + 1 < a.steps + a.warmup:
+                    for m in meta["outputs"] + meta["intermediates"]:
+                        m.free()
+            L = last["outputs"][0]
+            res[label] = {"ms": round(1e3 * min(times[a.warmup:]), 2), **matrix.RESIDENCY.stats()}
+            res[label + "_L"] = [be.to_host(L.get_tile(nt - 1, j)) for j in range(nt)]
+            A.free()
+        same = all(np.array_equal(x, y) for x, y in zip(res.pop("resident_L"), res.pop("budget_L")))
+        matrix.RESIDENCY.set_budget(None)
+        print(json.dumps({"what": f"host-DRAM tier, {b}^2 fp64 tiles ({b * b * 8 >> 20} MiB)",
+                          "d2h_pinned_GB/s": round(max(out), 1), "h2d_pinned_GB/s": round(max(back), 1),
+                          "both_directions_GB/s": round(max(both), 1),
+                          "cholesky": f"{n}^2, {nt}x{nt} tiles", "resident": res["resident"], "budget": res["budget"],
+                          "budget_tiles": a.budget_tiles, "last_block_row_bitwise_equal": bool(same),
+                          "pinned_bytes": be.pinned_bytes}))
     else:
         sys.argv = [sys.argv[0], "--tiles", str(a.tiles), "--tile", str(b), "--steps", str(a.steps), "--warmup", str(a.warmup),
                     "--no-cpu-baseline"]
