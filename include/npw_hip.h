@@ -168,13 +168,16 @@ size_t npw_dpotrf_lower_workspace_bytes(int64_t n);
 int npw_dpotrf_lower(int64_t n, const double* A, int64_t lda, double* Lout, int64_t ldl,
                      int32_t* info_dev, void* workspace, npw_stream_t stream);
 
-/* Householder QR with compact-WY T of the m x n matrix A (m >= n), LAPACK
+/* Householder QR with compact-WY T of the m x n matrix A, LAPACK
  * DGEQRT3 conventions (H_j = I - tau_j v_j v_j^T, beta = -sign(alpha)*norm):
  *   V (m x n, ldv): unit-lower-trapezoidal Householder vectors (diag = 1, upper = 0)
  *   T (n x n, ldt): upper triangular, Q = I - V T V^T      (strictly-lower = 0)
  *   R (n x n, ldr): upper triangular factor                 (strictly-lower = 0)
  * A is not modified.  Replaces kernels.qr_factor -> fast_qr (reference
- * numpywren/kernels.py:86-105,127-130; f2py dgeqrt3 + post-processing).        */
+ * numpywren/kernels.py:86-105,127-130; f2py dgeqrt3 + post-processing).
+ * m < n (the reference's slow_qr, kernels.py:67-84: DGEQRF + DLARFT): k = m reflectors
+ * from the leading m x m block; V is m x m, T m x m and R the m x n upper trapezoid
+ * [R1 | Q^T A2] (ldv, ldt >= m; ldr >= n).                                       */
 size_t npw_dgeqrt_workspace_bytes(int64_t m, int64_t n);
 int npw_dgeqrt(int64_t m, int64_t n, const double* A, int64_t lda, double* V, int64_t ldv,
                double* T, int64_t ldt, double* R, int64_t ldr, void* workspace,

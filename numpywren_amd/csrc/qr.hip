@@ -334,6 +334,8 @@ extern "C" {
 
 size_t npw_dgeqrt_workspace_bytes(int64_t m, int64_t n) {
     if (m <= 0 || n <= 0) return 0;
+    if (m < n)  // wide: the square factorisation of the leading block + two m x (n - m) GEMM temporaries
+        return npw_dgeqrt_workspace_bytes(m, m) + 2 * align2((size_t)m * (n - m)) * sizeof(double);
     const size_t doubles = 2 * align2((size_t)PB * n) + align2((size_t)n * n) +
                            align2((size_t)((n + 1) / 2 + PB) * n) + align2((size_t)4 * ceil_div(m, SLAB) * PB) +
                            4 * PB + 34 * PB * PB;
@@ -345,9 +347,26 @@ int npw_dgeqrt(int64_t m, int64_t n, const double* A, int64_t lda, double* V, in
                npw_stream_t stream) {
     NPW_REQUIRE(m >= 0 && n >= 0, "npw_dgeqrt: negative dimension");
     if (n == 0) return NPW_OK;
-    if (m < n) return set_error(NPW_ERR_UNSUPPORTED, "npw_dgeqrt: m (%lld) < n (%lld) is not supported",
-                                (long long)m, (long long)n);
+    if (m == 0) return NPW_OK;
     NPW_REQUIRE(A && V && T && R && workspace, "npw_dgeqrt: NULL argument");
+    if (m < n) {
+        // More columns than rows (reference kernels.py:94-95 -> slow_qr 67-84: DGEQRF + DLARFT): k = m reflectors, all
+        // of them determined by the leading m x m block A1; the other columns only receive Q^T:
+        //   V (m x m), T (m x m), R = [R1 | A2 - V (T^T (V^T A2))]  (m x n upper trapezoid).
+        NPW_REQUIRE(lda >= n && ldr >= n && ldv >= m && ldt >= m, "npw_dgeqrt: leading dimension too small");
+        NPW_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "npw_dgeqrt: workspace not 16B aligned");
+        const int64_t n2 = n - m;
+        int rc = npw_dgeqrt(m, m, A, lda, V, ldv, T, ldt, R, ldr, workspace, stream);
+        if (rc) return rc;
+        double* X = reinterpret_cast<double*>(static_cast<char*>(workspace) + npw_dgeqrt_workspace_bytes(m, m));
+        double* W = X + align2((size_t)m * n2);
+        hipStream_t s2 = as_stream(stream);
+        rc = gemm<double>('T', 'N', m, n2, m, 1.0, V, ldv, A + m, lda, 0.0, nullptr, 0, X, n2, GemmOpts(), s2);
+        if (rc) return rc;
+        rc = gemm<double>('T', 'N', m, n2, m, 1.0, T, ldt, X, n2, 0.0, nullptr, 0, W, n2, GemmOpts(), s2);
+        if (rc) return rc;
+        return gemm<double>('N', 'N', m, n2, m, -1.0, V, ldv, W, n2, 1.0, A + m, lda, R + m, ldr, GemmOpts(), s2);
+    }
     NPW_REQUIRE(lda >= n && ldv >= n && ldt >= n && ldr >= n, "npw_dgeqrt: leading dimension too small");
     NPW_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "npw_dgeqrt: workspace not 16B aligned");
     NPW_REQUIRE((const void*)A != (const void*)V, "npw_dgeqrt: V must not alias A");

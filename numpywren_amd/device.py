@@ -894,22 +894,20 @@ class HipBackend(object):
         return out
 
     def geqrt(self, A, stream=None):
-        """Householder QR of the m x n tile (m >= n): returns (V m x n, T n x n, R n x n)."""
+        """Householder QR of the m x n tile with k = min(m, n) reflectors: returns (V m x k unit lower trapezoid,
+        T k x k, R k x n upper) -- for m >= n what the reference's fast_qr returns, for m < n its slow_qr."""
         self._require_2d(A, "qr_factor")
         sh = self._sh(stream)
         A = self.as_f64(A, sh)
         m, n = A.shape
-        if m < n:
-            raise NotImplementedError(
-                f"qr_factor of a {m} x {n} block (more columns than rows) is not supported by the HIP path; the "
-                "reference routes this case to slow_qr (numpywren/kernels.py:94-95) which no algorithm uses")
-        V = self.empty((m, n), _F64)
-        T = self.empty((n, n), _F64)
-        R = self.empty((n, n), _F64)
+        k = min(m, n)
+        V = self.empty((m, k), _F64)
+        T = self.empty((k, k), _F64)
+        R = self.empty((k, n), _F64)
         ws = self.alloc(max(16, self.lib.npw_dgeqrt_workspace_bytes(m, n)))
         ws.streams.add(sh)
         self._use(sh, A, V, T, R)
-        _ffi.check(self.lib.npw_dgeqrt(m, n, A.ptr, n, V.ptr, n, T.ptr, n, R.ptr, n, ws.ptr, sh), "geqrt")
+        _ffi.check(self.lib.npw_dgeqrt(m, n, A.ptr, n, V.ptr, k, T.ptr, k, R.ptr, n, ws.ptr, sh), "geqrt")
         self._produced(sh, V, T, R)
         return V, T, R
 

@@ -213,7 +213,8 @@ mul = _mul
 @_kernel
 def _qr_factor(be, stream, *blocks, **kwargs):
     """QR of vstack(blocks): (V unit-lower-trapezoid m x n, T n x n upper with Q = I - V T V^T,
-    R n x n upper) -- reference kernels.py:127-130 -> fast_qr 86-105 (LAPACK dgeqrt3)."""
+    R n x n upper) -- reference kernels.py:127-130 -> fast_qr 86-105 (LAPACK dgeqrt3).  A stack with more columns
+    than rows (fast_qr hands it to slow_qr, 94-95 -> 67-84) gives V m x m, T m x m and R m x n."""
     ins = be.vstack(list(blocks), stream)
     return be.geqrt(ins, stream)
 
@@ -359,9 +360,7 @@ chol._npw_needs_whole_cus = True   # see job_runner.LambdaPackExecutor.run_task
 # ------------------------------------------------------------------------------------------------
 # surface kept for import compatibility; not on the gemm / cholesky / tsqr / bdfac paths
 # ------------------------------------------------------------------------------------------------
-def slow_qr(x):
-    raise NotImplementedError("slow_qr (dgeqrf + dlarft for n > m; reference kernels.py:67-84) is not used by any "
-                              "LambdaPACK program and has no HIP implementation yet")
+slow_qr = _qr_factor   # reference kernels.py:67-84 (DGEQRF + DLARFT): same (V, T, R); npw_dgeqrt takes any m, n
 
 
 @_kernel

@@ -181,6 +181,29 @@ def test_qr_factor_vs_oracle(m, n):
     np.testing.assert_allclose(Q.T @ Q, np.eye(m), atol=1e-11 * m)
 
 
+@pytest.mark.parametrize("m,n", [(8, 12), (32, 33), (64, 200), (100, 256), (256, 512)])
+def test_qr_factor_wide_vs_oracle(m, n):
+    """More columns than rows: the reference's fast_qr hands over to slow_qr (kernels.py:94-95 -> 67-84)."""
+    rng = np.random.default_rng(m * n)
+    A = rng.standard_normal((m, n))
+    V, T, R = kernels.qr_factor(A)
+    assert V.shape == (m, m) and T.shape == (m, m) and R.shape == (m, n)
+    Vr, Tr, Rr = oracle.qr_factor(A)
+    tol = 1e-11 * n
+    np.testing.assert_allclose(V, Vr, atol=tol)
+    np.testing.assert_allclose(T, Tr, atol=tol)
+    np.testing.assert_allclose(R, Rr, atol=tol * 10)
+    assert not np.triu(V, 1).any() and np.all(np.diag(V) == 1) and not np.tril(T, -1).any() and not np.tril(R, -1).any()
+    Q = np.eye(m) - V @ T @ V.T
+    np.testing.assert_allclose(Q @ R, A, atol=1e-11 * n)
+    np.testing.assert_allclose(Q.T @ Q, np.eye(m), atol=1e-11 * m)
+    for got, ref in zip(kernels.slow_qr(A), (Vr, Tr, Rr)):
+        np.testing.assert_allclose(got, ref, atol=tol * 10)
+    # lq_factor of a tall block is the same path transposed
+    for got, ref in zip(kernels.lq_factor(A.T.copy()), oracle.lq_factor(A.T.copy())):
+        np.testing.assert_allclose(got, ref, atol=tol * 10)
+
+
 def test_qr_family_vs_oracle():
     rng = np.random.default_rng(9)
     b = 48

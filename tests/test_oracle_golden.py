@@ -160,6 +160,33 @@ def test_block_indexing():
             assert oracle.shard_key(key_base, shape, shards, k["bidx"]) == k["key"]
 
 
+@pytest.mark.parametrize("m,n", [(5, 9), (16, 17), (32, 96), (64, 65)])
+def test_slow_qr_restatement_against_lapack_dgeqrt(m, n):
+    """The reference's slow_qr (kernels.py:67-84) needs an f2py DLARFT that cannot be had here; the restatement is
+    checked against real LAPACK instead: DGEQRT with nb = m factors the leading m x m block with one DGEQRT3 call and
+    applies Q^T to the other columns -- the same reflectors, the same compact-WY T, the same R."""
+    import scipy.linalg.lapack as lapack
+    rng = np.random.default_rng(m + 3 * n)
+    x = rng.standard_normal((m, n))
+    v, t, r = oracle.slow_qr(x)
+    assert v.shape == (m, m) and t.shape == (m, m) and r.shape == (m, n)
+    a, tt, info = lapack.dgeqrt(m, np.asfortranarray(x))
+    assert info == 0
+    vl = np.tril(a[:, :m], -1) + np.eye(m)
+    np.testing.assert_allclose(v, vl, atol=1e-13)
+    np.testing.assert_allclose(r, np.triu(a), atol=1e-12)
+    np.testing.assert_allclose(t, np.triu(tt), atol=1e-12)
+    q = np.eye(m) - v @ t @ v.T
+    np.testing.assert_allclose(q @ r, x, atol=1e-12)
+    # fast_qr routes wide inputs here, as the reference does
+    for got, ref in zip(oracle.fast_qr(x), (v, t, r)):
+        assert np.array_equal(got, ref)
+    # and tall inputs agree between the two routes (DGEQRT3 vs DGEQRF + DLARFT)
+    y = rng.standard_normal((n, m))
+    for got, ref in zip(oracle.slow_qr(y), oracle.fast_qr(y)):
+        np.testing.assert_allclose(got, ref, atol=1e-12)
+
+
 # ---- blocked QR path (SURVEY 8f item 2): qr_factor_triangular and the QR program -------------------------------
 QRG = np.load(os.path.join(os.path.dirname(__file__), "golden", "qr.npz"))
 
