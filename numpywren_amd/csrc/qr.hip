@@ -21,7 +21,8 @@
 namespace npw {
 namespace {
 
-constexpr int PB = 32;
+constexpr int PB = 32;    // panel width (columns one thread keeps in registers)
+constexpr int OB = 128;   // outer block: PB-wide panels are aggregated into one OB-wide block reflector for the far columns
 __device__ inline double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -249,28 +250,38 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
 }
 
 struct QrWorkspace {
-    double* X1;   // PB x n
-    double* X2;   // PB x n
-    double* G;    // n x n   (V^T V)
+    double* X1;   // OB x n
+    double* X2;   // OB x n
+    double* G;    // n x n   (V^T V; split-K scratch of the far updates before that)
     double* Tmp;  // (n/2 rounded up) x n
+    double* Gb;   // OB x OB: V_b^T V_b of the current outer block
     double* Part;    // 2 x slabs x PB hand-off slots (16 bytes each) of the panel kernel
     double* RowBuf;  // 2 x PB slots: the next pivot row
-    double* Xn;      // (2 + 32) x PB x PB: scratch (X1, X2, split-K partials) of the look-ahead update
+    double* Xn;      // (2 + 32) x PB x 2 OB: scratch (X1, X2, split-K partials) of the near updates
 };
 
 inline size_t align2(size_t x) { return (x + 1) & ~(size_t)1; }
+
+constexpr size_t XN_DOUBLES = (size_t)34 * PB * 2 * OB;
+
+size_t square_workspace_doubles(int64_t m, int64_t n) {
+    return 2 * align2((size_t)OB * n) + align2((size_t)n * n) + align2((size_t)((n + 1) / 2 + PB) * n) +
+           (size_t)OB * OB + align2((size_t)4 * ceil_div(m, SLAB) * PB) + 4 * PB + XN_DOUBLES;
+}
 
 QrWorkspace carve(void* ws, int64_t m, int64_t n) {
     QrWorkspace q;
     double* p = static_cast<double*>(ws);
     q.X1 = p;
-    p += align2((size_t)PB * n);
+    p += align2((size_t)OB * n);
     q.X2 = p;
-    p += align2((size_t)PB * n);
+    p += align2((size_t)OB * n);
     q.G = p;
     p += align2((size_t)n * n);
     q.Tmp = p;
     p += align2((size_t)((n + 1) / 2 + PB) * n);
+    q.Gb = p;
+    p += (size_t)OB * OB;
     q.Part = p;
     p += align2((size_t)4 * ceil_div(m, SLAB) * PB);
     q.RowBuf = p;
@@ -279,21 +290,22 @@ QrWorkspace carve(void* ws, int64_t m, int64_t n) {
     return q;
 }
 
-// T[lo:hi, lo:hi] is built from panel blocks by merging halves:
+// T[lo:hi, lo:hi] is built from its final `leaf`-wide diagonal blocks by merging halves:
 //   T12 = -T1 * G[lo:mid, mid:hi] * T2        (T1, T2 upper triangular, already final)
-int merge_t(int64_t lo, int64_t hi, double* T, int64_t ldt, const double* G, int64_t ldg, double* Tmp,
-            hipStream_t s) {
-    const int64_t npanels = ceil_div(hi - lo, PB);
-    if (npanels <= 1) return NPW_OK;
-    const int64_t mid = lo + (npanels / 2) * PB;
-    int rc = merge_t(lo, mid, T, ldt, G, ldg, Tmp, s);
+// G holds V^T V for the columns g0.. (G[0][0] is the entry of column g0 with itself).
+int merge_t(int64_t lo, int64_t hi, int64_t leaf, double* T, int64_t ldt, const double* G, int64_t ldg, int64_t g0,
+            double* Tmp, hipStream_t s) {
+    const int64_t nleaves = ceil_div(hi - lo, leaf);
+    if (nleaves <= 1) return NPW_OK;
+    const int64_t mid = lo + (nleaves / 2) * leaf;
+    int rc = merge_t(lo, mid, leaf, T, ldt, G, ldg, g0, Tmp, s);
     if (rc) return rc;
-    rc = merge_t(mid, hi, T, ldt, G, ldg, Tmp, s);
+    rc = merge_t(mid, hi, leaf, T, ldt, G, ldg, g0, Tmp, s);
     if (rc) return rc;
     const int64_t w1 = mid - lo, w2 = hi - mid;
     // Tmp (w1 x w2) = G12 * T2
-    rc = gemm<double>('N', 'N', w1, w2, w2, 1.0, G + lo * ldg + mid, ldg, T + mid * ldt + mid, ldt, 0.0, nullptr,
-                      0, Tmp, w2, GemmOpts(), s);
+    rc = gemm<double>('N', 'N', w1, w2, w2, 1.0, G + (lo - g0) * ldg + (mid - g0), ldg, T + mid * ldt + mid, ldt, 0.0,
+                      nullptr, 0, Tmp, w2, GemmOpts(), s);
     if (rc) return rc;
     // T12 = -T1 * Tmp
     return gemm<double>('N', 'N', w1, w2, w1, -1.0, T + lo * ldt + lo, ldt, Tmp, w2, 0.0, nullptr, 0,
@@ -336,9 +348,7 @@ size_t npw_dgeqrt_workspace_bytes(int64_t m, int64_t n) {
     if (m <= 0 || n <= 0) return 0;
     if (m < n)  // wide: the square factorisation of the leading block + two m x (n - m) GEMM temporaries
         return npw_dgeqrt_workspace_bytes(m, m) + 2 * align2((size_t)m * (n - m)) * sizeof(double);
-    const size_t doubles = 2 * align2((size_t)PB * n) + align2((size_t)n * n) +
-                           align2((size_t)((n + 1) / 2 + PB) * n) + align2((size_t)4 * ceil_div(m, SLAB) * PB) +
-                           4 * PB + 34 * PB * PB;
+    const size_t doubles = square_workspace_doubles(m, n);
     return doubles * sizeof(double);
 }
 
@@ -389,44 +399,68 @@ int npw_dgeqrt(int64_t m, int64_t n, const double* A, int64_t lda, double* V, in
         if (rc) return rc;
         NPW_HIP_CHECK(hipEventRecord(side->join, s));  // so that the closing wait is valid for a single panel
     }
-    for (int64_t j0 = 0; j0 < n; j0 += PB) {
-        const int64_t pb = (n - j0 < PB) ? n - j0 : PB;
-        const int64_t mp = m - j0;
-        double* Wp = V + j0 * ldv + j0;
-        {
+    // Two levels of blocking.  The panel chain (latency-bound: one small persistent launch per PB columns) runs on the
+    // caller's stream and keeps only the columns it needs soon up to date -- the rest of its own OB-wide block and the
+    // whole next block ("near" columns, PB-wide reflectors, three small GEMMs per panel).  Everything further right
+    // ("far") is updated once per OB columns on the side stream with the block reflector (V_b, T_b): k = OB GEMMs that
+    // read and write the big trailing matrix OB/PB times less often than per-panel updates would.
+    for (int64_t b0 = 0; b0 < n; b0 += OB) {
+        const int64_t ob = (n - b0 < OB) ? n - b0 : OB;
+        const int64_t near_end = (b0 + ob + OB < n) ? b0 + ob + OB : n;  // end of the next block
+        for (int64_t j0 = b0; j0 < b0 + ob; j0 += PB) {
+            const int64_t pb = (b0 + ob - j0 < PB) ? b0 + ob - j0 : PB;
+            const int64_t mp = m - j0;
+            double* Wp = V + j0 * ldv + j0;
             const int G = (int)ceil_div(mp, SLAB);
             hipLaunchKernelGGL(qr_panel3_kernel, dim3(G), dim3(SLAB), 0, s, (int)mp, (int)pb, Wp, ldv, T + j0 * ldt + j0, ldt,
                                R + j0 * ldr + j0, ldr, reinterpret_cast<slot_t*>(q.Part), reinterpret_cast<slot_t*>(q.RowBuf),
                                call_tag + (unsigned long long)(j0 / PB) * 64);
             NPW_LAUNCH_CHECK();
+            const int64_t nc = near_end - j0 - pb;
+            if (nc > 0) {
+                // the next block's columns were last written by the side stream (far update of the previous block):
+                // waiting here, not before the panel kernel, gives that update one panel time of slack
+                if (j0 == b0 && b0 > 0 && near_end > b0 + ob) NPW_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
+                int rc = apply_panel(Wp, ldv, mp, pb, T + j0 * ldt + j0, ldt, Wp + pb, nc, q.Xn, q.Xn + (size_t)PB * 2 * OB,
+                                     q.Xn + (size_t)2 * PB * 2 * OB, (size_t)32 * PB * 2 * OB, R + j0 * ldr + j0 + pb, ldr, s);
+                if (rc) return rc;
+            }
         }
-        const int64_t n2 = n - j0 - pb;
-        if (n2 > 0) {
-            // Trailing update  W2 -= V_p (T_p^T (V_p^T W2))  with look-ahead: the next panel's columns are updated on
-            // the caller's stream, so the next panel kernel (latency-bound, <= 32 small workgroups) can start while
-            // the side stream updates the rest of the trailing matrix with chip-filling GEMMs.
-            double* W2 = Wp + pb;
-            const int64_t nn = (n2 < PB) ? n2 : PB;  // columns of the next panel
-            if (j0 > 0) NPW_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));  // rest(j-1) touched these columns
-            int rc = apply_panel(Wp, ldv, mp, pb, T + j0 * ldt + j0, ldt, W2, nn, q.Xn, q.Xn + PB * PB, q.Xn + 2 * PB * PB,
-                                 (size_t)32 * PB * PB, R + j0 * ldr + j0 + pb, ldr, s);
-            if (rc) return rc;
-            if (n2 > nn) {
-                NPW_HIP_CHECK(hipEventRecord(side->fork, s));
-                NPW_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
-                rc = apply_panel(Wp, ldv, mp, pb, T + j0 * ldt + j0, ldt, W2 + nn, n2 - nn, q.X1, q.X2, q.G,
-                                 (size_t)n * n, R + j0 * ldr + j0 + pb + nn, ldr, side->stream);
+        const int64_t nfar = n - near_end;
+        if (ob > PB || nfar > 0) {
+            // block reflector on the side stream: T_b from the Gram matrix of the block's columns, then the far update
+            NPW_HIP_CHECK(hipEventRecord(side->fork, s));
+            NPW_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+            const int64_t mb = m - b0;
+            double* Vb = V + b0 * ldv + b0;
+            if (ob > PB) {
+                GemmOpts sk;
+                int64_t want = mb / 256;
+                if (want > 32) want = 32;
+                if (want > (int64_t)OB * n / (ob * ob)) want = (int64_t)OB * n / (ob * ob);
+                if (want > 1) {  // ob x ob output with a contraction over all rows: split k (scratch: X1, free until the far update)
+                    sk.splitk = (int)want;
+                    sk.splitk_ws = q.X1;
+                }
+                int rc = gemm<double>('T', 'N', ob, ob, mb, 1.0, Vb, ldv, Vb, ldv, 0.0, nullptr, 0, q.Gb, OB, sk, side->stream);
+                if (rc) return rc;
+                rc = merge_t(b0, b0 + ob, PB, T, ldt, q.Gb, OB, b0, q.Tmp, side->stream);
+                if (rc) return rc;
+            }
+            if (nfar > 0) {
+                int rc = apply_panel(Vb, ldv, mb, ob, T + b0 * ldt + b0, ldt, V + b0 * ldv + near_end, nfar, q.X1, q.X2, q.G,
+                                     (size_t)n * n, R + b0 * ldr + near_end, ldr, side->stream);
                 if (rc) return rc;
             }
             NPW_HIP_CHECK(hipEventRecord(side->join, side->stream));
         }
     }
     NPW_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
-    if (n > PB) {
-        // G = V^T V, then the off-diagonal blocks of T bottom-up
+    if (n > OB) {
+        // G = V^T V, then the off-diagonal OB-blocks of T bottom-up (the diagonal ones are final)
         int rc = gemm<double>('T', 'N', n, n, m, 1.0, V, ldv, V, ldv, 0.0, nullptr, 0, q.G, n, GemmOpts(), s);
         if (rc) return rc;
-        rc = merge_t(0, n, T, ldt, q.G, n, q.Tmp, s);
+        rc = merge_t(0, n, OB, T, ldt, q.G, n, 0, q.Tmp, s);
         if (rc) return rc;
     }
     return NPW_OK;

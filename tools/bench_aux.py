@@ -26,10 +26,13 @@ from numpywren_amd.device import get_backend  # noqa: E402
 from numpywren_amd.matrix import BigMatrix  # noqa: E402
 
 
+STREAMS = 1
+
+
 def run(program, reclaim=True):
     program.config["executor"]["reclaim_intermediates"] = reclaim
     program.start()
-    job_runner.lambdapack_run(program, timeout=3600)
+    job_runner.lambdapack_run(program, timeout=3600, pipeline_width=STREAMS)
     if program.program_status() != lp.PS.SUCCESS:
         raise SystemExit(f"failed: {program.exceptions}")
 
@@ -65,7 +68,11 @@ def main():
     ap.add_argument("--tile", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams of the executor (pipeline_width)")
     a = ap.parse_args()
+    global STREAMS
+    STREAMS = a.streams
+    os.environ.setdefault("NUMPYWREN_AMD_STREAMS", str(max(4, a.streams)))
     be = get_backend()
     b = a.tile
     if a.what == "gemm32":
@@ -107,7 +114,7 @@ def main():
         flops = 2 * m * b * b - 2 * b ** 3 / 3
         print(json.dumps({"what": f"{m} x {b} fp64 TSQR (alg_wrappers.tsqr), {a.leaves} leaves, {2 * a.leaves - 1} tasks",
                           "ms": round(dt * 1e3, 2), "TFLOP/s(2mn^2-2n^3/3)": round(flops / dt / 1e12, 3),
-                          "rel_err_RtR": float(err)}))
+                          "rel_err_RtR": float(err), "streams": a.streams}))
     elif a.what == "spill":
         from numpywren_amd import matrix
         # 1. the copies themselves: one tile out to pinned memory and back, on the spill stream
