@@ -183,6 +183,19 @@ int npw_dgeqrt(int64_t m, int64_t n, const double* A, int64_t lda, double* V, in
                double* T, int64_t ldt, double* R, int64_t ldr, void* workspace,
                npw_stream_t stream);
 
+/* `count` independent QR factorisations of equal shape (m >= n) in lock step: one sequence of
+ * launches serves the whole batch (the panel kernel runs count x slabs workgroups, every GEMM
+ * is a strided batch), so the latency-bound panel chain is paid once per batch instead of once
+ * per matrix -- the leaves and the tree levels of TSQR (reference algs.py:30-36) are such
+ * batches.  A: HOST array of `count` device pointers (ld lda each).  Matrix z of the outputs
+ * lives at V + z * stride_v (elements), T + z * stride_t, R + z * stride_r; each result is
+ * what npw_dgeqrt returns for A[z].  workspace: npw_dgeqrt_batched_workspace_bytes bytes.    */
+size_t npw_dgeqrt_batched_workspace_bytes(int count, int64_t m, int64_t n);
+int npw_dgeqrt_batched(int count, int64_t m, int64_t n, const double* const* A, int64_t lda,
+                       double* V, int64_t ldv, int64_t stride_v, double* T, int64_t ldt,
+                       int64_t stride_t, double* R, int64_t ldr, int64_t stride_r,
+                       void* workspace, npw_stream_t stream);
+
 /* out = sum_i in[i]   (count operands of rows x cols each; fp64 accumulate/output).
  * in_is_f32[i] != 0 marks a float32 operand (the reference's add_matrices always
  * produces float64: np.zeros(args[0].shape) += a).  in pointers are HOST arrays of

@@ -74,6 +74,9 @@ PROTOTYPES = {
     "npw_dpotrf_lower": (c_int, [_i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "npw_dgeqrt_workspace_bytes": (_sz, [_i64, _i64]),
     "npw_dgeqrt": (c_int, [_i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "npw_dgeqrt_batched_workspace_bytes": (_sz, [c_int, _i64, _i64]),
+    "npw_dgeqrt_batched": (c_int, [c_int, _i64, _i64, POINTER(_vp), _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64,
+                                   _vp, _vp]),
     "npw_add_n": (c_int, [c_int, POINTER(_vp), POINTER(_i64), POINTER(c_int32), _i64, _i64, _vp, _i64, _vp]),
     "npw_add_diag": (c_int, [_vp, _i64, _i64, _i64, c_double, _vp]),
     "npw_is_zero": (c_int, [_vp, _i64, _i64, _i64, c_double, _vp, _vp]),

@@ -15,6 +15,9 @@ DEFAULTS = {
         "priority_stream": False,
         "exact_zero_shortcircuit": True,  # reproduce the reference's allclose(x, 0) early-outs
         "reclaim_intermediates": False,   # free intermediate tiles after their last reader
+        # Ready tasks of one latency-bound kind (qr_factor: the TSQR leaves, the nodes of a tree level) that are
+        # handed to the device as a single batched launch sequence; 1 = one task at a time.
+        "batch_tasks": 8,
     },
     "store": {
         "tier": "hbm",           # "hbm" (device memory) or "host" (pinned/pageable host memory)

@@ -82,8 +82,17 @@ __device__ inline void ld_slots4(const slot_t* p0, const slot_t* p1, const slot_
 
 __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double* W, int64_t ldw, double* Tjj, int64_t ldt,
                                                          double* Rjj, int64_t ldr, slot_t* part /* [2][G][PB] */,
-                                                         slot_t* rowbuf /* [2][PB] */, unsigned long long tag0) {
+                                                         slot_t* rowbuf /* [2][PB] */, unsigned long long tag0,
+                                                         int64_t sW, int64_t sT, int64_t sR, int64_t sPart, int64_t sRow) {
     constexpr int CLD = SLAB + 8;
+    {   // blockIdx.y = matrix of a batch of independent factorisations (each with its own hand-off slots)
+        const int64_t z = blockIdx.y;
+        W += z * sW;
+        Tjj += z * sT;
+        Rjj += z * sR;
+        part += z * sPart;
+        rowbuf += z * sRow;
+    }
     __shared__ double q[PB], d[PB], hh[3], Tl[PB * PB];
     __shared__ double cols[PB * CLD];
     const int tid = threadIdx.x;
@@ -249,91 +258,224 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
     }
 }
 
+// Element strides between the matrices of a batch of independent factorisations (count == 1: unused).
+struct Batch {
+    int count = 1;
+    int64_t sV = 0, sT = 0, sR = 0;
+};
+
+// Scratch of `count` factorisations, one array per purpose (matrix z at base + z * stride): the batched GEMMs need a
+// constant stride per operand, and their split-K partials want the per-matrix regions back to back.
 struct QrWorkspace {
-    double* X1;   // OB x n
+    double* X1;   // OB x n      far update temporaries; split-K scratch of the block Gram matrix
     double* X2;   // OB x n
-    double* G;    // n x n   (V^T V; split-K scratch of the far updates before that)
-    double* Tmp;  // (n/2 rounded up) x n
-    double* Gb;   // OB x OB: V_b^T V_b of the current outer block
+    double* G;    // n x n       V^T V; split-K scratch of the far updates before that
+    double* Tmp;  // (n/2 rounded up + PB) x n
+    double* Gb;   // OB x OB     V_b^T V_b of the current outer block
     double* Part;    // 2 x slabs x PB hand-off slots (16 bytes each) of the panel kernel
     double* RowBuf;  // 2 x PB slots: the next pivot row
-    double* Xn;      // (2 + 32) x PB x 2 OB: scratch (X1, X2, split-K partials) of the near updates
+    double* XnA;     // PB x 2 OB   near update temporaries
+    double* XnB;     // PB x 2 OB
+    double* XnS;     // 32 x PB x 2 OB  split-K partials of the near updates
+    int64_t sX, sG, sTmp, sGb, sPart, sRow, sXn, sXnS;
 };
 
 inline size_t align2(size_t x) { return (x + 1) & ~(size_t)1; }
 
-constexpr size_t XN_DOUBLES = (size_t)34 * PB * 2 * OB;
-
-size_t square_workspace_doubles(int64_t m, int64_t n) {
-    return 2 * align2((size_t)OB * n) + align2((size_t)n * n) + align2((size_t)((n + 1) / 2 + PB) * n) +
-           (size_t)OB * OB + align2((size_t)4 * ceil_div(m, SLAB) * PB) + 4 * PB + XN_DOUBLES;
+QrWorkspace carve(void* ws, int64_t m, int64_t n, int count) {
+    QrWorkspace q;
+    q.sX = (int64_t)align2((size_t)OB * n);
+    q.sG = (int64_t)align2((size_t)n * n);
+    q.sTmp = (int64_t)align2((size_t)((n + 1) / 2 + PB) * n);
+    q.sGb = (int64_t)OB * OB;
+    q.sPart = (int64_t)align2((size_t)4 * ceil_div(m, SLAB) * PB);
+    q.sRow = 4 * PB;
+    q.sXn = (int64_t)PB * 2 * OB;
+    q.sXnS = (int64_t)32 * PB * 2 * OB;
+    double* p = static_cast<double*>(ws);
+    auto take = [&](int64_t stride) {
+        double* r = p;
+        p += (size_t)stride * count;
+        return r;
+    };
+    q.X1 = take(q.sX);
+    q.X2 = take(q.sX);
+    q.G = take(q.sG);
+    q.Tmp = take(q.sTmp);
+    q.Gb = take(q.sGb);
+    q.Part = take(q.sPart);
+    q.RowBuf = take(q.sRow);
+    q.XnA = take(q.sXn);
+    q.XnB = take(q.sXn);
+    q.XnS = take(q.sXnS);
+    return q;
 }
 
-QrWorkspace carve(void* ws, int64_t m, int64_t n) {
-    QrWorkspace q;
-    double* p = static_cast<double*>(ws);
-    q.X1 = p;
-    p += align2((size_t)OB * n);
-    q.X2 = p;
-    p += align2((size_t)OB * n);
-    q.G = p;
-    p += align2((size_t)n * n);
-    q.Tmp = p;
-    p += align2((size_t)((n + 1) / 2 + PB) * n);
-    q.Gb = p;
-    p += (size_t)OB * OB;
-    q.Part = p;
-    p += align2((size_t)4 * ceil_div(m, SLAB) * PB);
-    q.RowBuf = p;
-    p += 4 * PB;
-    q.Xn = p;
-    return q;
+size_t square_workspace_doubles(int64_t m, int64_t n) {
+    const QrWorkspace q = carve(nullptr, m, n, 0);   // count 0: only the strides are of interest
+    return (size_t)(2 * q.sX + q.sG + q.sTmp + q.sGb + q.sPart + q.sRow + 2 * q.sXn + q.sXnS);
+}
+
+inline GemmOpts batched(const Batch& b, int64_t sa, int64_t sb, int64_t sc, int64_t sd) {
+    GemmOpts o;
+    if (b.count > 1) {
+        o.batch = b.count;
+        o.batch_a = sa;
+        o.batch_b = sb;
+        o.batch_c = sc;
+        o.batch_d = sd;
+    }
+    return o;
 }
 
 // T[lo:hi, lo:hi] is built from its final `leaf`-wide diagonal blocks by merging halves:
 //   T12 = -T1 * G[lo:mid, mid:hi] * T2        (T1, T2 upper triangular, already final)
 // G holds V^T V for the columns g0.. (G[0][0] is the entry of column g0 with itself).
-int merge_t(int64_t lo, int64_t hi, int64_t leaf, double* T, int64_t ldt, const double* G, int64_t ldg, int64_t g0,
-            double* Tmp, hipStream_t s) {
+int merge_t(const Batch& b, int64_t lo, int64_t hi, int64_t leaf, double* T, int64_t ldt, const double* G, int64_t ldg,
+            int64_t sG, int64_t g0, double* Tmp, int64_t sTmp, hipStream_t s) {
     const int64_t nleaves = ceil_div(hi - lo, leaf);
     if (nleaves <= 1) return NPW_OK;
     const int64_t mid = lo + (nleaves / 2) * leaf;
-    int rc = merge_t(lo, mid, leaf, T, ldt, G, ldg, g0, Tmp, s);
+    int rc = merge_t(b, lo, mid, leaf, T, ldt, G, ldg, sG, g0, Tmp, sTmp, s);
     if (rc) return rc;
-    rc = merge_t(mid, hi, leaf, T, ldt, G, ldg, g0, Tmp, s);
+    rc = merge_t(b, mid, hi, leaf, T, ldt, G, ldg, sG, g0, Tmp, sTmp, s);
     if (rc) return rc;
     const int64_t w1 = mid - lo, w2 = hi - mid;
     // Tmp (w1 x w2) = G12 * T2
     rc = gemm<double>('N', 'N', w1, w2, w2, 1.0, G + (lo - g0) * ldg + (mid - g0), ldg, T + mid * ldt + mid, ldt, 0.0,
-                      nullptr, 0, Tmp, w2, GemmOpts(), s);
+                      nullptr, 0, Tmp, w2, batched(b, sG, b.sT, 0, sTmp), s);
     if (rc) return rc;
     // T12 = -T1 * Tmp
     return gemm<double>('N', 'N', w1, w2, w1, -1.0, T + lo * ldt + lo, ldt, Tmp, w2, 0.0, nullptr, 0,
-                        T + lo * ldt + mid, ldt, GemmOpts(), s);
+                        T + lo * ldt + mid, ldt, batched(b, b.sT, sTmp, 0, b.sT), s);
+}
+
+// The top `rows` rows of the updated columns are final rows of R: move them to R and clear them in the working matrix
+// (they lie above the diagonal of V).  blockIdx.z = matrix of the batch.
+__global__ void move_rows_kernel(int rows, int64_t cols, double* W, int64_t ldw, int64_t sW, double* Rd, int64_t ldr,
+                                 int64_t sR) {
+    W += (int64_t)blockIdx.z * sW;
+    Rd += (int64_t)blockIdx.z * sR;
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+        Rd[(int64_t)r * ldr + c] = W[(int64_t)r * ldw + c];
+        W[(int64_t)r * ldw + c] = 0.0;
+    }
 }
 
 // W2 (mp x nc, ld ldv) -= V_p (T_p^T (V_p^T W2)), then its top pb rows (final rows of R) move to Rdst and are
-// zeroed in place (V is zero there).  X1, X2: pb x nc scratch; skws: optional split-K scratch of skcap elements.
-int apply_panel(const double* Wp, int64_t ldv, int64_t mp, int64_t pb, const double* Tjj, int64_t ldt, double* W2,
-                int64_t nc, double* X1, double* X2, double* skws, size_t skcap, double* Rdst, int64_t ldr, hipStream_t s) {
+// zeroed in place (V is zero there).  X1, X2: pb x nc scratch per matrix (strides sX1, sX2); skws: split-K scratch of
+// skcap elements per matrix, the matrices' regions back to back.
+int apply_panel(const Batch& b, const double* Wp, int64_t ldv, int64_t mp, int64_t pb, const double* Tjj, int64_t ldt,
+                double* W2, int64_t nc, double* X1, int64_t sX1, double* X2, int64_t sX2, double* skws, size_t skcap,
+                double* Rdst, int64_t ldr, hipStream_t s) {
     // X1 = V_p^T W2 is pb x nc with a contraction over all mp rows: split k so that the launch has a few hundred
     // workgroups instead of nc/64
-    GemmOpts sk;
-    int64_t want = 512 / (ceil_div(nc, 64) > 0 ? ceil_div(nc, 64) : 1);
+    GemmOpts g1 = batched(b, b.sV, b.sV, 0, sX1);
+    int64_t want = 512 / (ceil_div(nc, 64) * b.count > 0 ? ceil_div(nc, 64) * b.count : 1);
     if (want > mp / 256) want = mp / 256;
     if (want > 32) want = 32;
     if (skws != nullptr && want > 1 && (size_t)want * pb * nc <= skcap) {
-        sk.splitk = (int)want;
-        sk.splitk_ws = skws;
+        g1.splitk = (int)want;
+        g1.splitk_ws = skws;
     }
-    int rc = gemm<double>('T', 'N', pb, nc, mp, 1.0, Wp, ldv, W2, ldv, 0.0, nullptr, 0, X1, nc, sk, s);
+    int rc = gemm<double>('T', 'N', pb, nc, mp, 1.0, Wp, ldv, W2, ldv, 0.0, nullptr, 0, X1, nc, g1, s);
     if (rc) return rc;
-    rc = gemm<double>('T', 'N', pb, nc, pb, 1.0, Tjj, ldt, X1, nc, 0.0, nullptr, 0, X2, nc, GemmOpts(), s);
+    rc = gemm<double>('T', 'N', pb, nc, pb, 1.0, Tjj, ldt, X1, nc, 0.0, nullptr, 0, X2, nc, batched(b, b.sT, sX1, 0, sX2), s);
     if (rc) return rc;
-    rc = gemm<double>('N', 'N', mp, nc, pb, -1.0, Wp, ldv, X2, nc, 1.0, W2, ldv, W2, ldv, GemmOpts(), s);
+    rc = gemm<double>('N', 'N', mp, nc, pb, -1.0, Wp, ldv, X2, nc, 1.0, W2, ldv, W2, ldv, batched(b, b.sV, sX2, b.sV, b.sV), s);
     if (rc) return rc;
-    NPW_HIP_CHECK(hipMemcpy2DAsync(Rdst, ldr * 8, W2, ldv * 8, nc * 8, pb, hipMemcpyDeviceToDevice, s));
-    NPW_HIP_CHECK(hipMemset2DAsync(W2, ldv * 8, 0, nc * 8, pb, s));
+    const unsigned gy = (unsigned)(pb < 32 ? pb : 32);
+    hipLaunchKernelGGL(move_rows_kernel, dim3((unsigned)ceil_div(nc, 256), gy, (unsigned)b.count), dim3(256), 0, s, (int)pb, nc,
+                       W2, ldv, b.sV, Rdst, ldr, b.sR);
+    NPW_LAUNCH_CHECK();
+    return NPW_OK;
+}
+
+// `b.count` independent m x n (m >= n) factorisations in lock step; the working copies are already in V, T and R are
+// cleared.  One sequence of launches serves the whole batch: the panel kernel runs count x slabs workgroups, every
+// GEMM is a strided batch.
+int geqrt_core(const Batch& b, int64_t m, int64_t n, double* V, int64_t ldv, double* T, int64_t ldt, double* R,
+               int64_t ldr, void* workspace, hipStream_t s) {
+    const QrWorkspace q = carve(workspace, m, n, b.count);
+
+    // sequence tags of the panel kernel's hand-off slots: unique per call (process-wide counter seeded from the
+    // clock), panel and column, so that stale slots in a recycled workspace can never look current
+    static std::atomic<unsigned long long> call_counter{
+        (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() & 0x3fffffffULL};
+    const unsigned long long call_tag = (call_counter.fetch_add(1) + 1) << 24;
+    SideStream* side = nullptr;
+    {
+        int rc = side_stream(s, &side);
+        if (rc) return rc;
+        NPW_HIP_CHECK(hipEventRecord(side->join, s));  // so that the closing wait is valid for a single block
+    }
+    // Two levels of blocking.  The panel chain (latency-bound: one small persistent launch per PB columns) runs on the
+    // caller's stream and keeps only the columns it needs soon up to date -- the rest of its own OB-wide block and the
+    // whole next block ("near" columns, PB-wide reflectors, three small GEMMs per panel).  Everything further right
+    // ("far") is updated once per OB columns on the side stream with the block reflector (V_b, T_b): k = OB GEMMs that
+    // read and write the big trailing matrix OB/PB times less often than per-panel updates would.
+    for (int64_t b0 = 0; b0 < n; b0 += OB) {
+        const int64_t ob = (n - b0 < OB) ? n - b0 : OB;
+        const int64_t near_end = (b0 + ob + OB < n) ? b0 + ob + OB : n;  // end of the next block
+        for (int64_t j0 = b0; j0 < b0 + ob; j0 += PB) {
+            const int64_t pb = (b0 + ob - j0 < PB) ? b0 + ob - j0 : PB;
+            const int64_t mp = m - j0;
+            double* Wp = V + j0 * ldv + j0;
+            const int G = (int)ceil_div(mp, SLAB);
+            hipLaunchKernelGGL(qr_panel3_kernel, dim3(G, b.count), dim3(SLAB), 0, s, (int)mp, (int)pb, Wp, ldv,
+                               T + j0 * ldt + j0, ldt, R + j0 * ldr + j0, ldr, reinterpret_cast<slot_t*>(q.Part),
+                               reinterpret_cast<slot_t*>(q.RowBuf), call_tag + (unsigned long long)(j0 / PB) * 64, b.sV, b.sT,
+                               b.sR, q.sPart / 2, q.sRow / 2);
+            NPW_LAUNCH_CHECK();
+            const int64_t nc = near_end - j0 - pb;
+            if (nc > 0) {
+                // the next block's columns were last written by the side stream (far update of the previous block):
+                // waiting here, not before the panel kernel, gives that update one panel time of slack
+                if (j0 == b0 && b0 > 0 && near_end > b0 + ob) NPW_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
+                int rc = apply_panel(b, Wp, ldv, mp, pb, T + j0 * ldt + j0, ldt, Wp + pb, nc, q.XnA, q.sXn, q.XnB, q.sXn,
+                                     q.XnS, (size_t)q.sXnS, R + j0 * ldr + j0 + pb, ldr, s);
+                if (rc) return rc;
+            }
+        }
+        const int64_t nfar = n - near_end;
+        if (ob > PB || nfar > 0) {
+            // block reflector on the side stream: T_b from the Gram matrix of the block's columns, then the far update
+            NPW_HIP_CHECK(hipEventRecord(side->fork, s));
+            NPW_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+            const int64_t mb = m - b0;
+            double* Vb = V + b0 * ldv + b0;
+            if (ob > PB) {
+                GemmOpts sk = batched(b, b.sV, b.sV, 0, q.sGb);
+                int64_t want = mb / 256;
+                if (want > 32) want = 32;
+                if (want > q.sX / (ob * ob)) want = q.sX / (ob * ob);
+                if (want > 1) {  // ob x ob output with a contraction over all rows: split k (scratch: X1, free until the far update)
+                    sk.splitk = (int)want;
+                    sk.splitk_ws = q.X1;
+                }
+                int rc = gemm<double>('T', 'N', ob, ob, mb, 1.0, Vb, ldv, Vb, ldv, 0.0, nullptr, 0, q.Gb, OB, sk, side->stream);
+                if (rc) return rc;
+                rc = merge_t(b, b0, b0 + ob, PB, T, ldt, q.Gb, OB, q.sGb, b0, q.Tmp, q.sTmp, side->stream);
+                if (rc) return rc;
+            }
+            if (nfar > 0) {
+                int rc = apply_panel(b, Vb, ldv, mb, ob, T + b0 * ldt + b0, ldt, V + b0 * ldv + near_end, nfar, q.X1, q.sX, q.X2,
+                                     q.sX, q.G, (size_t)q.sG, R + b0 * ldr + near_end, ldr, side->stream);
+                if (rc) return rc;
+            }
+            NPW_HIP_CHECK(hipEventRecord(side->join, side->stream));
+        }
+    }
+    NPW_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
+    if (n > OB) {
+        // G = V^T V, then the off-diagonal OB-blocks of T bottom-up (the diagonal ones are final)
+        int rc = gemm<double>('T', 'N', n, n, m, 1.0, V, ldv, V, ldv, 0.0, nullptr, 0, q.G, n, batched(b, b.sV, b.sV, 0, q.sG), s);
+        if (rc) return rc;
+        rc = merge_t(b, 0, n, OB, T, ldt, q.G, n, q.sG, 0, q.Tmp, q.sTmp, s);
+        if (rc) return rc;
+    }
     return NPW_OK;
 }
 
@@ -348,8 +490,7 @@ size_t npw_dgeqrt_workspace_bytes(int64_t m, int64_t n) {
     if (m <= 0 || n <= 0) return 0;
     if (m < n)  // wide: the square factorisation of the leading block + two m x (n - m) GEMM temporaries
         return npw_dgeqrt_workspace_bytes(m, m) + 2 * align2((size_t)m * (n - m)) * sizeof(double);
-    const size_t doubles = square_workspace_doubles(m, n);
-    return doubles * sizeof(double);
+    return square_workspace_doubles(m, n) * sizeof(double);
 }
 
 int npw_dgeqrt(int64_t m, int64_t n, const double* A, int64_t lda, double* V, int64_t ldv,
@@ -381,89 +522,50 @@ int npw_dgeqrt(int64_t m, int64_t n, const double* A, int64_t lda, double* V, in
     NPW_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "npw_dgeqrt: workspace not 16B aligned");
     NPW_REQUIRE((const void*)A != (const void*)V, "npw_dgeqrt: V must not alias A");
     hipStream_t s = as_stream(stream);
-    const QrWorkspace q = carve(workspace, m, n);
-
     // working copy: the factorisation runs in place inside V
     NPW_HIP_CHECK(hipMemcpy2DAsync(V, ldv * 8, A, lda * 8, n * 8, m, hipMemcpyDeviceToDevice, s));
     NPW_HIP_CHECK(hipMemset2DAsync(T, ldt * 8, 0, n * 8, n, s));
     NPW_HIP_CHECK(hipMemset2DAsync(R, ldr * 8, 0, n * 8, n, s));
+    return geqrt_core(Batch(), m, n, V, ldv, T, ldt, R, ldr, workspace, s);
+}
 
-    // sequence tags of the panel kernel's hand-off slots: unique per call (process-wide counter seeded from the
-    // clock), panel and column, so that stale slots in a recycled workspace can never look current
-    static std::atomic<unsigned long long> call_counter{
-        (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() & 0x3fffffffULL};
-    const unsigned long long call_tag = (call_counter.fetch_add(1) + 1) << 24;
-    SideStream* side = nullptr;
-    {
-        int rc = side_stream(s, &side);
-        if (rc) return rc;
-        NPW_HIP_CHECK(hipEventRecord(side->join, s));  // so that the closing wait is valid for a single panel
+size_t npw_dgeqrt_batched_workspace_bytes(int count, int64_t m, int64_t n) {
+    if (count <= 0 || m <= 0 || n <= 0 || m < n) return 0;
+    return (size_t)count * square_workspace_doubles(m, n) * sizeof(double);
+}
+
+int npw_dgeqrt_batched(int count, int64_t m, int64_t n, const double* const* A, int64_t lda, double* V, int64_t ldv,
+                       int64_t stride_v, double* T, int64_t ldt, int64_t stride_t, double* R, int64_t ldr,
+                       int64_t stride_r, void* workspace, npw_stream_t stream) {
+    NPW_REQUIRE(count >= 0 && m >= 0 && n >= 0, "npw_dgeqrt_batched: negative argument");
+    if (count == 0 || n == 0 || m == 0) return NPW_OK;
+    NPW_REQUIRE(m >= n, "npw_dgeqrt_batched: m (%lld) < n (%lld): use npw_dgeqrt", (long long)m, (long long)n);
+    NPW_REQUIRE(count <= 65535, "npw_dgeqrt_batched: more than 65535 matrices");
+    NPW_REQUIRE(A && V && T && R && workspace, "npw_dgeqrt_batched: NULL argument");
+    NPW_REQUIRE(lda >= n && ldv >= n && ldt >= n && ldr >= n, "npw_dgeqrt_batched: leading dimension too small");
+    NPW_REQUIRE(stride_v >= m * ldv && stride_t >= n * ldt && stride_r >= n * ldr, "npw_dgeqrt_batched: stride too small");
+    NPW_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "npw_dgeqrt_batched: workspace not 16B aligned");
+    hipStream_t s = as_stream(stream);
+    for (int z = 0; z < count; ++z) {
+        NPW_REQUIRE(A[z] != nullptr, "npw_dgeqrt_batched: A[%d] is NULL", z);
+        NPW_HIP_CHECK(hipMemcpy2DAsync(V + (int64_t)z * stride_v, ldv * 8, A[z], lda * 8, n * 8, m, hipMemcpyDeviceToDevice, s));
     }
-    // Two levels of blocking.  The panel chain (latency-bound: one small persistent launch per PB columns) runs on the
-    // caller's stream and keeps only the columns it needs soon up to date -- the rest of its own OB-wide block and the
-    // whole next block ("near" columns, PB-wide reflectors, three small GEMMs per panel).  Everything further right
-    // ("far") is updated once per OB columns on the side stream with the block reflector (V_b, T_b): k = OB GEMMs that
-    // read and write the big trailing matrix OB/PB times less often than per-panel updates would.
-    for (int64_t b0 = 0; b0 < n; b0 += OB) {
-        const int64_t ob = (n - b0 < OB) ? n - b0 : OB;
-        const int64_t near_end = (b0 + ob + OB < n) ? b0 + ob + OB : n;  // end of the next block
-        for (int64_t j0 = b0; j0 < b0 + ob; j0 += PB) {
-            const int64_t pb = (b0 + ob - j0 < PB) ? b0 + ob - j0 : PB;
-            const int64_t mp = m - j0;
-            double* Wp = V + j0 * ldv + j0;
-            const int G = (int)ceil_div(mp, SLAB);
-            hipLaunchKernelGGL(qr_panel3_kernel, dim3(G), dim3(SLAB), 0, s, (int)mp, (int)pb, Wp, ldv, T + j0 * ldt + j0, ldt,
-                               R + j0 * ldr + j0, ldr, reinterpret_cast<slot_t*>(q.Part), reinterpret_cast<slot_t*>(q.RowBuf),
-                               call_tag + (unsigned long long)(j0 / PB) * 64);
-            NPW_LAUNCH_CHECK();
-            const int64_t nc = near_end - j0 - pb;
-            if (nc > 0) {
-                // the next block's columns were last written by the side stream (far update of the previous block):
-                // waiting here, not before the panel kernel, gives that update one panel time of slack
-                if (j0 == b0 && b0 > 0 && near_end > b0 + ob) NPW_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
-                int rc = apply_panel(Wp, ldv, mp, pb, T + j0 * ldt + j0, ldt, Wp + pb, nc, q.Xn, q.Xn + (size_t)PB * 2 * OB,
-                                     q.Xn + (size_t)2 * PB * 2 * OB, (size_t)32 * PB * 2 * OB, R + j0 * ldr + j0 + pb, ldr, s);
-                if (rc) return rc;
-            }
-        }
-        const int64_t nfar = n - near_end;
-        if (ob > PB || nfar > 0) {
-            // block reflector on the side stream: T_b from the Gram matrix of the block's columns, then the far update
-            NPW_HIP_CHECK(hipEventRecord(side->fork, s));
-            NPW_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
-            const int64_t mb = m - b0;
-            double* Vb = V + b0 * ldv + b0;
-            if (ob > PB) {
-                GemmOpts sk;
-                int64_t want = mb / 256;
-                if (want > 32) want = 32;
-                if (want > (int64_t)OB * n / (ob * ob)) want = (int64_t)OB * n / (ob * ob);
-                if (want > 1) {  // ob x ob output with a contraction over all rows: split k (scratch: X1, free until the far update)
-                    sk.splitk = (int)want;
-                    sk.splitk_ws = q.X1;
-                }
-                int rc = gemm<double>('T', 'N', ob, ob, mb, 1.0, Vb, ldv, Vb, ldv, 0.0, nullptr, 0, q.Gb, OB, sk, side->stream);
-                if (rc) return rc;
-                rc = merge_t(b0, b0 + ob, PB, T, ldt, q.Gb, OB, b0, q.Tmp, side->stream);
-                if (rc) return rc;
-            }
-            if (nfar > 0) {
-                int rc = apply_panel(Vb, ldv, mb, ob, T + b0 * ldt + b0, ldt, V + b0 * ldv + near_end, nfar, q.X1, q.X2, q.G,
-                                     (size_t)n * n, R + b0 * ldr + near_end, ldr, side->stream);
-                if (rc) return rc;
-            }
-            NPW_HIP_CHECK(hipEventRecord(side->join, side->stream));
-        }
+    if (stride_t == n * ldt && ldt == n) {
+        NPW_HIP_CHECK(hipMemsetAsync(T, 0, (size_t)count * n * n * 8, s));
+    } else {
+        for (int z = 0; z < count; ++z) NPW_HIP_CHECK(hipMemset2DAsync(T + (int64_t)z * stride_t, ldt * 8, 0, n * 8, n, s));
     }
-    NPW_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
-    if (n > OB) {
-        // G = V^T V, then the off-diagonal OB-blocks of T bottom-up (the diagonal ones are final)
-        int rc = gemm<double>('T', 'N', n, n, m, 1.0, V, ldv, V, ldv, 0.0, nullptr, 0, q.G, n, GemmOpts(), s);
-        if (rc) return rc;
-        rc = merge_t(0, n, OB, T, ldt, q.G, n, 0, q.Tmp, s);
-        if (rc) return rc;
+    if (stride_r == n * ldr && ldr == n) {
+        NPW_HIP_CHECK(hipMemsetAsync(R, 0, (size_t)count * n * n * 8, s));
+    } else {
+        for (int z = 0; z < count; ++z) NPW_HIP_CHECK(hipMemset2DAsync(R + (int64_t)z * stride_r, ldr * 8, 0, n * 8, n, s));
     }
-    return NPW_OK;
+    Batch b;
+    b.count = count;
+    b.sV = stride_v;
+    b.sT = stride_t;
+    b.sR = stride_r;
+    return geqrt_core(b, m, n, V, ldv, T, ldt, R, ldr, workspace, s);
 }
 
 }  // extern "C"

@@ -129,19 +129,20 @@ class _Ready(tuple):
 
 class DeviceTile(object):
     """One tile resident in HBM: a C-contiguous array of `shape`/`dtype` inside a DeviceBuffer."""
-    __slots__ = ("buf", "shape", "dtype", "ready", "zero_flag", "shared", "__weakref__")
+    __slots__ = ("buf", "shape", "dtype", "offset", "ready", "zero_flag", "shared", "__weakref__")
 
-    def __init__(self, buf, shape, dtype):
+    def __init__(self, buf, shape, dtype, offset=0):
         self.buf = buf
         self.shape = tuple(int(s) for s in shape)
         self.dtype = np.dtype(dtype)
+        self.offset = int(offset)   # bytes into the buffer (the outputs of a batched kernel share one allocation)
         self.ready = None       # (event_handle, stream_handle) of the producing kernel
         self.zero_flag = None   # DeviceBuffer holding the cached np.allclose(tile, 0) flag (int32)
         self.shared = False     # True for cached constant tiles that must never be written in place
 
     @property
     def ptr(self):
-        return self.buf.ptr
+        return self.buf.ptr + self.offset
 
     @property
     def nbytes(self):
@@ -167,7 +168,7 @@ class DeviceTile(object):
         """A second handle on the same buffer with a different (same-size) shape."""
         shape = tuple(int(s) for s in shape)
         assert int(np.prod(shape, dtype=np.int64)) == self.size, (shape, self.shape)
-        t = DeviceTile(self.buf, shape, self.dtype)
+        t = DeviceTile(self.buf, shape, self.dtype, self.offset)
         t.ready = self.ready
         t.zero_flag = self.zero_flag
         t.shared = self.shared
@@ -549,7 +550,7 @@ class HipBackend(object):
         """Start an asynchronous copy of `tile` into pinned host memory (after its producer) and return the
         SpilledTile that stands for it.  The device buffer goes back to the pool once every holder has dropped
         the tile and the copy has left the spill stream."""
-        kept = tile.buf.aux.get("host_copy") if isinstance(tile.buf.aux, dict) else None
+        kept = tile.buf.aux.get("host_copy") if (isinstance(tile.buf.aux, dict) and tile.offset == 0) else None
         if kept is not None and kept.nbytes == tile.nbytes and kept.dtype == tile.dtype:
             return kept if kept.shape == tile.shape else SpilledTile(kept.buf, tile.shape, tile.dtype, kept.ready)
         sp = self.spill_stream()
@@ -771,14 +772,15 @@ class HipBackend(object):
         # the inverses of L's diagonal blocks are computed once per factor and shared by every trsm
         # task that uses it (a whole block column of the Cholesky DAG)
         aux = L.buf.aux if L.buf.aux is not None else {}
-        cached = aux.get("diag_inv")
+        cached = aux.get("diag_inv") if L.offset == 0 else None   # the cache belongs to the tile at the buffer's start
         if cached is None:
             winv = self.alloc(max(16, self.lib.npw_dtrtri_diag_bytes(n)))
             winv.streams.add(sh)
             _ffi.check(self.lib.npw_dtrtri_diag(n, L.ptr, n, winv.ptr, sh), "trtri_diag")
             cached = (winv, (self.record_new(sh), sh))
-            aux["diag_inv"] = cached
-            L.buf.aux = aux
+            if L.offset == 0:
+                aux["diag_inv"] = cached
+                L.buf.aux = aux
         winv, ready = cached
         if ready is not None and ready[1] != sh:
             self.wait_event(sh, ready[0])
@@ -910,6 +912,31 @@ class HipBackend(object):
         _ffi.check(self.lib.npw_dgeqrt(m, n, A.ptr, n, V.ptr, k, T.ptr, k, R.ptr, n, ws.ptr, sh), "geqrt")
         self._produced(sh, V, T, R)
         return V, T, R
+
+    def geqrt_batched(self, As, stream=None):
+        """QR of several tiles of one shape (m >= n) in lock step (npw_dgeqrt_batched): [(V, T, R), ...], each triple
+        what `geqrt` returns for that tile.  The outputs of a batch share three allocations."""
+        sh = self._sh(stream)
+        As = [self.as_f64(a, sh) for a in As]
+        for a in As:
+            self._require_2d(a, "qr_factor")
+        m, n = As[0].shape
+        if len(As) == 1 or m < n or any(a.shape != (m, n) for a in As):
+            return [self.geqrt(a, stream) for a in As]
+        count = len(As)
+        vb, tb, rb = m * n * 8, n * n * 8, n * n * 8
+        Vbuf, Tbuf, Rbuf = self.alloc(count * vb), self.alloc(count * tb), self.alloc(count * rb)
+        ws = self.alloc(max(16, self.lib.npw_dgeqrt_batched_workspace_bytes(count, m, n)))
+        self._use(sh, *As)
+        for b in (Vbuf, Tbuf, Rbuf, ws):
+            b.streams.add(sh)
+        ptrs = (ctypes.c_void_p * count)(*[a.ptr for a in As])
+        _ffi.check(self.lib.npw_dgeqrt_batched(count, m, n, ptrs, n, Vbuf.ptr, n, m * n, Tbuf.ptr, n, n * n, Rbuf.ptr, n, n * n,
+                                               ws.ptr, sh), "geqrt_batched")
+        out = [(DeviceTile(Vbuf, (m, n), _F64, z * vb), DeviceTile(Tbuf, (n, n), _F64, z * tb),
+                DeviceTile(Rbuf, (n, n), _F64, z * rb)) for z in range(count)]
+        self._produced(sh, *[t for triple in out for t in triple])
+        return out
 
     def tri(self, tile, uplo, unit_diag=False, stream=None):
         """np.triu / np.tril of a 2-D fp64 tile as a new tile; unit_diag forces ones on the diagonal."""

@@ -81,6 +81,7 @@ class LambdaPackExecutor(object):
         cfg = (program.config or {}).get("executor", {}) if isinstance(program.config, dict) else {}
         self.exact_zero = cfg.get("exact_zero_shortcircuit", True) if exact_zero is None else exact_zero
         self.reclaim = cfg.get("reclaim_intermediates", False)
+        self.batch_tasks = max(1, int(cfg.get("batch_tasks", 8)))
         pool = getattr(self.be, "bulk_streams", None) or self.be.streams
         n = max(1, min(int(pipeline_width), len(pool)))
         self.streams = pool[:n]
@@ -203,6 +204,49 @@ class LambdaPackExecutor(object):
         self._consumed(task)
         return last
 
+    # ---- several independent tasks of one kind as one batched kernel call ----
+    def batch_fn(self, expr_idx):
+        """The batched implementation of the task's kernel, or None (no batching configured / kernel has none)."""
+        if self.batch_tasks <= 1 or self.program.block_sparse:
+            return None
+        return getattr(self.compiled.kernel(expr_idx), "_npw_batch", None)
+
+    def run_batch(self, nodes):
+        """Run the ready tasks `nodes` (all of the same expr_idx, whose kernel has a `_npw_batch`) with one call.
+        Same reads, writes and bookkeeping as run_task for each of them."""
+        expr_idx = nodes[0][0]
+        compute = self.compiled.kernel(expr_idx)
+        mats = self.compiled.matrices
+        stream = self.pick_stream(compute)
+        tasks = [self.compiled.task(e, v) for e, v in nodes]
+        arg_lists, kwargs_list, read_bytes = [], [], 0
+        for task in tasks:
+            tiles = [mats[m].get_tile(*idx, stream=stream) for m, idx in task.reads]
+            read_bytes += sum(t.nbytes for t in tiles)
+            arg_lists.append([tiles[j] if kind == "tile" else task.consts[j] for kind, j in task.arg_kinds])
+            kwargs_list.append(task.kwargs)
+        with kernels.stream_scope(stream, self.program.info_flags_sink(tasks[0]), self.exact_zero):
+            results = compute._npw_batch(self.be, stream, arg_lists, kwargs_list)
+        flops_fn = getattr(compute, "flops", None)
+        last, write_bytes = None, 0
+        for task, args, res in zip(tasks, arg_lists, results):
+            if flops_fn is not None:
+                try:
+                    self.program.incr_flops(flops_fn(*[a for a in args if not isinstance(a, (int, float))]))
+                except Exception:
+                    pass
+            res = res if isinstance(res, tuple) else (res,)
+            if len(res) != len(task.writes):
+                raise Exception("Expected {0} results, got {1}".format(len(task.writes), len(res)))
+            for (m, idx), r in zip(task.writes, res):
+                mats[m].put_tile(r, *idx)
+                write_bytes += r.nbytes
+                last = r
+            self._consumed(task)
+        self.program.incr_read(read_bytes)
+        self.program.incr_write(write_bytes)
+        return last
+
     async def run(self, expr_idx, var_values, computer=None, profile=True):
         """Reference-shaped entry point (job_runner.py:78): run one task and its eager successors."""
         refs = [(expr_idx, var_values)]
@@ -288,19 +332,26 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
                 break
             e, v = node
             t0 = time.time()
-            program.set_node_status(e, v, lp.NS.RUNNING)
+            # independent ready tasks of the same latency-bound kind (TSQR leaves, the nodes of a tree level) go to
+            # the device as ONE batched launch sequence
+            group = [(e, v)]
+            if ex.batch_fn(e) is not None:
+                group += program.dequeue_matching(lambda e2, v2: e2 == e, ex.batch_tasks - 1)
+            for ge, gv in group:
+                program.set_node_status(ge, gv, lp.NS.RUNNING)
             try:
-                last = ex.run_task(e, v)
+                last = ex.run_batch(group) if len(group) > 1 else ex.run_task(e, v)
             except Exception as exc:
                 tb = traceback.format_exc()
                 program.handle_exception(exc, tb=tb, expr_idx=e, var_values=v)
                 raise
             # stream order + tile events already encode "children run after me" on the device, so
             # the host can release the children immediately
-            program.post_op(e, v, lp.PS.SUCCESS, None)
-            program.set_node_status(e, v, lp.NS.FINISHED)
-            executed.append([e, v])
-            refs.append((e, v))
+            for ge, gv in group:
+                program.post_op(ge, gv, lp.PS.SUCCESS, None)
+                program.set_node_status(ge, gv, lp.NS.FINISHED)
+                executed.append([ge, gv])
+                refs.append((ge, gv))
             running_times.append((t0, time.time()))
             if last is not None and last.ready is not None:
                 inflight.append(last)

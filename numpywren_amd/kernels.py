@@ -223,6 +223,17 @@ qr_factor = _qr_factor
 fast_qr = _qr_factor
 
 
+def _qr_factor_batch(be, stream, arg_lists, kwargs_list):
+    """Several independent qr_factor tasks as one batched launch sequence (npw_dgeqrt_batched): the TSQR leaves and
+    the nodes of one tree level (reference algs.py:30-36) are independent and latency-bound one by one.
+    arg_lists[i] are the block tiles of task i; returns [(V, T, R), ...] in the same order."""
+    ins = [be.vstack(list(blocks), stream) for blocks in arg_lists]
+    return be.geqrt_batched(ins, stream)
+
+
+qr_factor._npw_batch = _qr_factor_batch
+
+
 def _qr_flops(*blocks):
     m = sum(b.shape[0] for b in blocks)
     n = blocks[0].shape[1]

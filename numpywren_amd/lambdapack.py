@@ -341,6 +341,23 @@ class LambdaPackProgram(object):
                 return None
             return heapq.heappop(self._ready)[2]
 
+    def dequeue_matching(self, pred, limit):
+        """Up to `limit` further ready tasks with pred(expr_idx, vars) true, best priority first (the executor uses
+        this to run independent tasks of one kind as a single batched launch)."""
+        if limit <= 0:
+            return []
+        with self._lock:
+            taken, kept = [], []
+            for item in sorted(self._ready):
+                if len(taken) < limit and pred(item[2][0], item[2][1]):
+                    taken.append(item[2])
+                else:
+                    kept.append(item)
+            if taken:
+                self._ready = kept
+                heapq.heapify(self._ready)
+            return taken
+
     def num_ready(self):
         with self._lock:
             return len(self._ready)

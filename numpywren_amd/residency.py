@@ -44,8 +44,8 @@ class Residency(object):
 
     def __init__(self, table):
         self.table = table
-        self.lru = collections.OrderedDict()  # (bucket, key_base, tile_key) -> id of the tile's DeviceBuffer
-        self.bufs = {}                         # id(DeviceBuffer) -> [nbytes, {table keys}]
+        self.lru = collections.OrderedDict()  # (bucket, key_base, tile_key) -> (id of the tile's DeviceBuffer, offset)
+        self.bufs = {}                         # (id(DeviceBuffer), offset) -> [nbytes, {table keys}]
         self.resident_bytes = 0
         self._budget = None
         self._budget_known = False
@@ -100,7 +100,7 @@ class Residency(object):
         self.note_delete(tkey)
         if not self._evictable(obj):
             return
-        bid = id(obj.buf)
+        bid = (id(obj.buf), getattr(obj, "offset", 0))
         ent = self.bufs.get(bid)
         if ent is None:
             ent = self.bufs[bid] = [obj.nbytes, set()]
@@ -140,7 +140,7 @@ class Residency(object):
         if any(k in protect for k in keys):
             return 0
         live = [(k, self._lookup(k)) for k in keys]
-        live = [(k, o) for k, o in live if self._evictable(o) and id(o.buf) == bid]
+        live = [(k, o) for k, o in live if self._evictable(o) and (id(o.buf), getattr(o, "offset", 0)) == bid]
         for k in keys:
             self.note_delete(k)   # also drops entries the table no longer holds (cleared behind our back)
         if not live:

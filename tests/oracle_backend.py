@@ -181,6 +181,14 @@ class OracleBackend(object):
         v, t, r = oracle.fast_qr(A.array)
         return HostTile(v), HostTile(t), HostTile(r)
 
+    def geqrt_batched(self, As, stream=None):
+        self.calls.append(("geqrt_batched", len(As)))
+        out = []
+        for a in As:
+            v, t, r = oracle.fast_qr(a.array)
+            out.append((HostTile(v), HostTile(t), HostTile(r)))
+        return out
+
     def tri(self, tile, uplo, unit_diag=False, stream=None):
         a = np.triu(tile.array) if uplo.upper() == "U" else np.tril(tile.array)
         a = np.array(a, dtype=np.float64)

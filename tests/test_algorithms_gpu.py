@@ -323,3 +323,30 @@ def test_two_factorisations_in_flight(hbm_store):
         assert program.program_status() == lp.PS.SUCCESS
         L = np.tril(meta["outputs"][0].numpy())
         np.testing.assert_allclose(L, np.linalg.cholesky(A), rtol=1e-10, atol=1e-10)
+
+
+def test_tsqr_batched_tasks_match_one_by_one(hbm_store):
+    """The executor hands ready qr_factor tasks to the GPU in batches (executor.batch_tasks); R, V, T equal the
+    one-task-at-a-time run to rounding and the factor satisfies R^T R = X^T X."""
+    rng = np.random.default_rng(77)
+    b, leaves = 96, 16
+    Xh = rng.standard_normal((b * leaves, b))
+    res = {}
+    for width in (8, 1):
+        X = BigMatrix(f"tsqr_gpu_batch_{width}", shape=Xh.shape, shard_sizes=(b, b))
+        for j in range(leaves):
+            X.put_block(Xh[j * b:(j + 1) * b], j, 0)
+        program, meta = alg_wrappers.tsqr(X)
+        program.config["executor"]["batch_tasks"] = width
+        program.start()
+        out = job_runner.lambdapack_run(program)
+        program.wait()
+        assert program.program_status() == lp.PS.SUCCESS
+        assert len(out["executed_messages"]) == 2 * leaves - 1
+        R, V, T = meta["outputs"]
+        res[width] = (R.get_block(4, 0), V.get_block(4, 0), T.get_block(2, 4), V.get_block(0, 5))
+        program.free()
+    for a, c in zip(res[8], res[1]):
+        np.testing.assert_allclose(a, c, atol=1e-12, rtol=0)
+    R = res[8][0]
+    np.testing.assert_allclose(R.T @ R, Xh.T @ Xh, atol=1e-10 * np.linalg.norm(Xh) ** 2)

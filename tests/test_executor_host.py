@@ -126,6 +126,54 @@ def test_tsqr(tag, b, oracle_backend):
     np.testing.assert_allclose(T.get_block(0, 0), ALG[f"tsqr_{tag}/T_leaf0"], atol=1e-12)
 
 
+def test_tsqr_leaves_and_tree_levels_run_as_batches(oracle_backend):
+    """Ready qr_factor tasks are grouped (config executor.batch_tasks, default 8) into one batched call; the task
+    set, the order constraints and the results are those of the one-by-one run."""
+    Xh = ALG["tsqr_64_8/X"]
+    outs = {}
+    for width in (8, 3, 1):
+        matrix_key = f"tsqr_batch_{width}"
+        X = BigMatrix(matrix_key, shape=Xh.shape, shard_sizes=(8, Xh.shape[1]))
+        shard_matrix(X, Xh)
+        program, meta = alg_wrappers.tsqr(X)
+        program.config["executor"]["batch_tasks"] = width
+        del oracle_backend.calls[:]
+        res = run(program)
+        assert program.program_status() == lp.PS.SUCCESS
+        assert len(res["executed_messages"]) == 15            # 8 leaves + 4 + 2 + 1
+        sizes = [c[1] for c in oracle_backend.calls if c[0] == "geqrt_batched"]
+        singles = sum(1 for c in oracle_backend.calls if c[0] == "geqrt")
+        assert sum(sizes) + singles == 15
+        if width == 8:
+            assert sizes == [8, 4, 2] and singles == 1
+        elif width == 3:
+            assert max(sizes) == 3
+        else:
+            assert sizes == [] and singles == 15
+        R, V, T = meta["outputs"]
+        outs[width] = (R.get_block(3, 0), V.get_block(3, 0), T.get_block(0, 0))
+        np.testing.assert_allclose(outs[width][0], ALG["tsqr_64_8/R_final"], atol=1e-12)
+    for w in (3, 1):
+        for a, b in zip(outs[8], outs[w]):
+            assert np.array_equal(a, b)
+
+
+def test_dequeue_matching_takes_best_priority_first(oracle_backend):
+    Xh = ALG["tsqr_64_8/X"]
+    X = BigMatrix("tsqr_dq", shape=Xh.shape, shard_sizes=(8, Xh.shape[1]))
+    shard_matrix(X, Xh)
+    program, _ = alg_wrappers.tsqr(X)
+    program.start()
+    assert program.num_ready() == 8
+    first = program.dequeue()
+    more = program.dequeue_matching(lambda e, v: e == first[0], 3)
+    assert len(more) == 3 and program.num_ready() == 4
+    assert program.dequeue_matching(lambda e, v: False, 5) == [] and program.num_ready() == 4
+    assert program.dequeue_matching(lambda e, v: True, 0) == []
+    rest = program.dequeue_matching(lambda e, v: True, 100)
+    assert len(rest) == 4 and program.num_ready() == 0 and program.dequeue() is None
+
+
 def test_bdfac(oracle_backend):
     Xh = ALG["bdfac_16_4/X"]
     X = BigMatrix("bdfac_in", shape=Xh.shape, shard_sizes=(4, 4))

@@ -204,6 +204,38 @@ def test_qr_factor_wide_vs_oracle(m, n):
         np.testing.assert_allclose(got, ref, atol=tol * 10)
 
 
+@pytest.mark.parametrize("m,n,count", [(64, 64, 2), (200, 67, 5), (256, 128, 3), (512, 300, 4), (1024, 512, 9)])
+def test_qr_batched_equals_one_by_one(m, n, count):
+    """npw_dgeqrt_batched: `count` factorisations in lock step give what npw_dgeqrt gives for each (the same kernels
+    on the same data; only the split-k of the long reductions may regroup sums when the batch changes their grid)."""
+    be = kernels.get_backend()
+    rng = np.random.default_rng(m + n + count)
+    As = [rng.standard_normal((m, n)) for _ in range(count)]
+    tiles = [be.to_device(a) for a in As]
+    got = be.geqrt_batched(tiles)
+    assert len(got) == count
+    for a, t, (V, T, R) in zip(As, tiles, got):
+        V1, T1, R1 = be.geqrt(t)
+        for x, y in ((V, V1), (T, T1), (R, R1)):
+            np.testing.assert_allclose(be.to_host(x), be.to_host(y), atol=1e-12, rtol=0)
+        Vr, Tr, Rr = oracle.qr_factor(a)
+        tol = 1e-11 * max(m, n)
+        np.testing.assert_allclose(be.to_host(V), Vr, atol=tol)
+        np.testing.assert_allclose(be.to_host(T), Tr, atol=tol)
+        np.testing.assert_allclose(be.to_host(R), Rr, atol=tol * 10)
+    # the outputs of a batch share allocations: tiles must stay valid after their siblings are dropped
+    keep = got[-1]
+    want = [be.to_host(x) for x in keep]
+    del got
+    be.synchronize()
+    junk = [be.fill_random((m, n), 3) for _ in range(3)]
+    for x, w in zip(keep, want):
+        assert np.array_equal(be.to_host(x), w)
+    # mixed shapes and wide blocks fall back to one call each
+    mixed = be.geqrt_batched([tiles[0], be.to_device(rng.standard_normal((m + 8, n)))])
+    assert mixed[0][0].shape == (m, n) and mixed[1][0].shape == (m + 8, n)
+
+
 def test_qr_family_vs_oracle():
     rng = np.random.default_rng(9)
     b = 48
