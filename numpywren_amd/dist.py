@@ -51,6 +51,7 @@ def process_grid(world):
 
 class Comm(object):
     """Tile exchange over torch.distributed (payload: RCCL for device tensors, gloo on CPU)."""
+    ownership = None  # optional algorithm-aware map (matrix_name, idx) -> rank or None (see tsqr_ownership)
 
     def __init__(self, rank, world, backend, device_tensors):
         import torch
@@ -66,6 +67,10 @@ class Comm(object):
 
     # ---- ownership ----
     def owner(self, matrix_name, idx):
+        if self.ownership is not None:
+            r = self.ownership(matrix_name, tuple(idx))
+            if r is not None:
+                return r
         pr, pc = self.grid
         if len(idx) >= 2:
             return (idx[-2] % pr) * pc + (idx[-1] % pc)
@@ -206,6 +211,24 @@ def _consumer_ranks(comm, task):
     return out
 
 
+def tsqr_ownership(world, num_leaves, input_name="A"):
+    """Ownership for the TSQR program (reference algs.py:30-36): the leaves are dealt out in contiguous chunks
+    (num_leaves / world each) and a tree node lives where its left operand lives.  The first log2(chunk) levels of the
+    tree are then local to a GPU (and independent across its leaves: the executor batches them), and only the last
+    log2(world) levels move one R factor per pair of GPUs -- the tree all-reduce of SURVEY 8(e).  The generic
+    block-cyclic map would scatter every level.  Install with `comm.ownership = tsqr_ownership(...)`."""
+    def chunk(j):
+        return min(world - 1, int(j) * world // max(1, int(num_leaves)))
+
+    def own(name, idx):
+        if name == input_name:
+            return chunk(idx[0])              # A[j, 0]
+        if name in ("Vs", "Ts", "Rs") and len(idx) == 2:
+            return chunk(idx[1])              # X[level, j]
+        return None
+    return own
+
+
 def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, max_inflight=64):
     """Distributed counterpart of job_runner.lambdapack_run: every rank calls it with the same program."""
     program.incr_up(1)
@@ -247,33 +270,41 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
                 program._enqueue(node)
                 break
             e, v = node
-            task = compiled.task(e, v)
-            owner = comm.owner(*task.writes[0]) if task.writes else 0
-            program.set_node_status(e, v, lp.NS.RUNNING)
-            if rank == owner:
+            # every rank forms the same group of ready tasks of one batchable kind and runs its own members of it as
+            # one batched launch sequence; the exchange plan below is then walked in the common order
+            group = [(e, v)]
+            if ex.batch_fn(e) is not None:
+                group += program.dequeue_matching(lambda e2, v2: e2 == e, ex.batch_tasks * comm.world - 1)
+            tasks = [compiled.task(ge, gv) for ge, gv in group]
+            owners = [comm.owner(*t.writes[0]) if t.writes else 0 for t in tasks]
+            mine = [g for g, o in zip(group, owners) if o == rank]
+            for ge, gv in group:
+                program.set_node_status(ge, gv, lp.NS.RUNNING)
+            if mine:
                 try:
-                    last = ex.run_task(e, v)
+                    last = ex.run_batch(mine) if len(mine) > 1 else ex.run_task(*mine[0])
                 except Exception as exc:
                     program.handle_exception(exc, tb=traceback.format_exc(), expr_idx=e, var_values=v)
                     raise
-                executed.append([e, v])
+                executed.extend([ge, gv] for ge, gv in mine)
                 if last is not None and last.ready is not None:
                     inflight.append(last)
                     if len(inflight) > max_inflight:
                         be.wait_tile(inflight.popleft())
             # push the outputs to the remote consumers: both sides evaluate the same static plan here
-            for pos, ranks in _consumer_ranks(comm, task).items():
-                name, idx = task.writes[pos]
-                if rank == owner:
-                    if mats[name].tile_exists(*idx):
-                        tile = mats[name].get_tile(*idx)
-                        for dst in ranks:
-                            comm.send_tile(tile, dst)
-                        ex.sent(name, idx)
-                elif rank in ranks:
-                    mats[name].put_tile(comm.recv_tile(owner), *idx)
-            program.post_op(e, v, lp.PS.SUCCESS, None)
-            program.set_node_status(e, v, lp.NS.FINISHED)
+            for (ge, gv), task, owner in zip(group, tasks, owners):
+                for pos, ranks in _consumer_ranks(comm, task).items():
+                    name, idx = task.writes[pos]
+                    if rank == owner:
+                        if mats[name].tile_exists(*idx):
+                            tile = mats[name].get_tile(*idx)
+                            for dst in ranks:
+                                comm.send_tile(tile, dst)
+                            ex.sent(name, idx)
+                    elif rank in ranks:
+                        mats[name].put_tile(comm.recv_tile(owner), *idx)
+                program.post_op(ge, gv, lp.PS.SUCCESS, None)
+                program.set_node_status(ge, gv, lp.NS.FINISHED)
         comm.flush()
         be.synchronize()
         ok = job_runner.check_info_flags(program, be)

@@ -84,6 +84,34 @@ def _worker(rank, world, port, scenario, outdir):
         flags = [None] * world
         comm.dist.all_gather_object(flags, bool(result.get("has_final")))
         assert sum(flags) >= 1
+    elif scenario == "tsqr_chunked":
+        # algorithm-aware ownership: contiguous leaf chunks, local sub-trees, log2(world) exchanged R factors
+        Xh = ALG["tsqr_64_8/X"]
+        X = BigMatrix("tsqr_in_c", shape=Xh.shape, shard_sizes=(8, 8))
+        comm.ownership = dist.tsqr_ownership(world, 8)
+        scatter_owned(X, Xh, "A")
+        assert len(X.block_idxs_exist) == 8 // world
+        program, meta = alg_wrappers.tsqr(X)
+        program.start()
+        be = device.get_backend()
+        res = dist.lambdapack_run_distributed(program, comm)
+        assert program.program_status() == lp.PS.SUCCESS, program.exceptions
+        # 8 leaves + 7 tree nodes; rank r runs its 8/world leaves, its local sub-tree, and rank 0 the top
+        local_nodes = 8 // world - 1
+        top = {2: [1, 0], 4: [2, 0, 1, 0]}[world][rank]
+        assert len(res["executed_messages"]) == 8 // world + local_nodes + top
+        # the leaves of a rank went to the device as one batch
+        sizes = [c[1] for c in be.calls if c[0] == "geqrt_batched"]
+        assert sizes and sizes[0] == 8 // world
+        # only R factors travel: one 8 x 8 tile per tree edge that crosses ranks
+        sent = [None] * world
+        comm.dist.all_gather_object(sent, res["bytes_sent"])
+        assert sum(sent) == (world - 1) * 8 * 8 * 8
+        R = meta["outputs"][0]
+        assert R.tile_exists(3, 0) == (rank == 0)
+        if rank == 0:
+            np.testing.assert_allclose(R.get_block(3, 0), ALG["tsqr_64_8/R_final"], atol=1e-12)
+        comm.ownership = None
     elif scenario == "gemm":
         A, B, C = ALG["gemm_40_8/A"], ALG["gemm_40_8/B"], ALG["gemm_40_8/C"]
         Ab = BigMatrix("gemm_A", shape=A.shape, shard_sizes=(8, 8))
@@ -130,6 +158,11 @@ def test_tsqr_sharded(tmp_path):
     _spawn(2, "tsqr", tmp_path)
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_tsqr_chunked_ownership_and_batches(world, tmp_path):
+    _spawn(world, "tsqr_chunked", tmp_path)
+
+
 def test_gemm_sharded(tmp_path):
     _spawn(2, "gemm", tmp_path)
 
@@ -151,3 +184,10 @@ def test_process_grid_and_ownership():
     assert c.owner("S", (3, 5, 2)) == c.owner("I", (5, 2)) == c.owner("O", (5, 2)) == (5 % 2) * 4 + 2
     owners = {c.owner("O", (j, k)) for j in range(16) for k in range(j + 1)}
     assert owners == set(range(8))
+    # TSQR: contiguous leaf chunks, a tree node lives with its left operand
+    from numpywren_amd.dist import tsqr_ownership
+    c.ownership = tsqr_ownership(8, 256)
+    assert [c.owner("A", (j, 0)) for j in (0, 31, 32, 255)] == [0, 0, 1, 7]
+    assert c.owner("Rs", (0, 33)) == 1 and c.owner("Rs", (5, 32)) == 1 and c.owner("Rs", (6, 0)) == 0
+    assert c.owner("Vs", (8, 0)) == 0 and c.owner("Ts", (7, 128)) == 4
+    assert c.owner("O", (5, 2)) == (5 % 2) * 4 + 2       # other matrices keep the block-cyclic map

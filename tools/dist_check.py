@@ -75,12 +75,17 @@ def main():
         report.append(("gemm", ok and err < 1e-12, f"rel err {err:.2e}"))
 
     # --- TSQR ----------------------------------------------------------------------------------------------------
-    leaves = max(4, world)
+    # leaves in contiguous chunks per rank (local sub-trees run as batches, only log2(world) R factors travel)
+    leaves = 4 * world
     Th = rng.standard_normal((leaves * b, b))
     Tm = BigMatrix("dist_check_T", shape=Th.shape, shard_sizes=(b, b))
-    _owned_scatter(Tm, Th, comm, rank)
+    comm.ownership = dist.tsqr_ownership(world, leaves)
+    for j in range(leaves):
+        if comm.owner("A", (j, 0)) == rank:
+            Tm.put_block(np.ascontiguousarray(Th[j * b:(j + 1) * b]), j, 0)
     program, meta = alg_wrappers.tsqr(Tm)
     ok, res = _run(program, comm)
+    comm.ownership = None
     levels = int(np.ceil(np.log2(leaves)))
     Rm = meta["outputs"][0]
     have = Rm.get_block(levels, 0) if Rm.tile_exists(levels, 0) else None
