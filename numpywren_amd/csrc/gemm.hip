@@ -111,6 +111,7 @@ struct GemmParams {
     int batch_inner;                                  // two-level batch: z -> (z / inner, z % inner)
     int64_t batch2_a, batch2_b, batch2_c, batch2_d;
     int b_lower_tri;                                  // k range of column tile n0 ends at n0 + BN
+    int k_from_diag;                                  // k range of tile (m0, n0) starts at max(m0, n0) (trapezoidal operands)
 };
 
 // XCD-aware + grouped mapping of the linear block id to an output tile.
@@ -215,7 +216,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
     const int li = lane & 15, lg = lane >> 4;
 
     // split-K: blockIdx.y selects the k range [kb, kend) and its own partial output
-    const int kb = p.k_chunk > 0 ? (int)blockIdx.y * p.k_chunk : 0;
+    int kb = p.k_chunk > 0 ? (int)blockIdx.y * p.k_chunk : 0;
+    if (p.k_from_diag) kb = max(kb, (max(m0, n0) / BK) * BK);  // V^T V with V lower trapezoidal: rows above are zero
     int kend = p.k_chunk > 0 ? min(p.K, kb + p.k_chunk) : p.K;
     if (p.b_lower_tri) kend = min(kend, n0 + BN);  // rows of W^T below the diagonal block are zero
     int nk = (kend - kb + BK - 1) / BK;
@@ -576,6 +578,7 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
     p.batch2_c = opts.batch2_c;
     p.batch2_d = opts.batch2_d;
     p.b_lower_tri = opts.b_lower_tri ? 1 : 0;
+    p.k_from_diag = opts.k_from_diag ? 1 : 0;
     p.tag = opts.tag;
     p.k_chunk = opts.k_chunk_;
     p.split_stride = opts.k_chunk_ > 0 ? m * n : 0;

@@ -330,7 +330,8 @@ inline GemmOpts batched(const Batch& b, int64_t sa, int64_t sb, int64_t sc, int6
 
 // T[lo:hi, lo:hi] is built from its final `leaf`-wide diagonal blocks by merging halves:
 //   T12 = -T1 * G[lo:mid, mid:hi] * T2        (T1, T2 upper triangular, already final)
-// G holds V^T V for the columns g0.. (G[0][0] is the entry of column g0 with itself).
+// G holds V^T V for the columns g0.. (G[0][0] is the entry of column g0 with itself); only its lower triangle is read
+// (G12 = G21^T), so the Gram GEMM may skip the tiles above the diagonal.
 int merge_t(const Batch& b, int64_t lo, int64_t hi, int64_t leaf, double* T, int64_t ldt, const double* G, int64_t ldg,
             int64_t sG, int64_t g0, double* Tmp, int64_t sTmp, hipStream_t s) {
     const int64_t nleaves = ceil_div(hi - lo, leaf);
@@ -341,8 +342,8 @@ int merge_t(const Batch& b, int64_t lo, int64_t hi, int64_t leaf, double* T, int
     rc = merge_t(b, mid, hi, leaf, T, ldt, G, ldg, sG, g0, Tmp, sTmp, s);
     if (rc) return rc;
     const int64_t w1 = mid - lo, w2 = hi - mid;
-    // Tmp (w1 x w2) = G12 * T2
-    rc = gemm<double>('N', 'N', w1, w2, w2, 1.0, G + (lo - g0) * ldg + (mid - g0), ldg, T + mid * ldt + mid, ldt, 0.0,
+    // Tmp (w1 x w2) = G12 * T2 = G21^T * T2
+    rc = gemm<double>('T', 'N', w1, w2, w2, 1.0, G + (mid - g0) * ldg + (lo - g0), ldg, T + mid * ldt + mid, ldt, 0.0,
                       nullptr, 0, Tmp, w2, batched(b, sG, b.sT, 0, sTmp), s);
     if (rc) return rc;
     // T12 = -T1 * Tmp
@@ -471,7 +472,12 @@ int geqrt_core(const Batch& b, int64_t m, int64_t n, double* V, int64_t ldv, dou
     NPW_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
     if (n > OB) {
         // G = V^T V, then the off-diagonal OB-blocks of T bottom-up (the diagonal ones are final)
-        int rc = gemm<double>('T', 'N', n, n, m, 1.0, V, ldv, V, ldv, 0.0, nullptr, 0, q.G, n, batched(b, b.sV, b.sV, 0, q.sG), s);
+        // (lower triangle only, and V is lower trapezoidal: tile (i0, j0) sums over the rows from max(i0, j0) on --
+        //  a sixth of the full product for a square matrix)
+        GemmOpts gg = batched(b, b.sV, b.sV, 0, q.sG);
+        gg.lower_only = true;
+        gg.k_from_diag = true;
+        int rc = gemm<double>('T', 'N', n, n, m, 1.0, V, ldv, V, ldv, 0.0, nullptr, 0, q.G, n, gg, s);
         if (rc) return rc;
         rc = merge_t(b, 0, n, OB, T, ldt, q.G, n, q.sG, 0, q.Tmp, q.sTmp, s);
         if (rc) return rc;
