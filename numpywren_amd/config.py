@@ -17,7 +17,7 @@ DEFAULTS = {
         "reclaim_intermediates": False,   # free intermediate tiles after their last reader
         # Ready tasks of one latency-bound kind (qr_factor: the TSQR leaves, the nodes of a tree level) that are
         # handed to the device as a single batched launch sequence; 1 = one task at a time.
-        "batch_tasks": 8,
+        "batch_tasks": 16,
     },
     "store": {
         "tier": "hbm",           # "hbm" (device memory) or "host" (pinned/pageable host memory)

@@ -18,9 +18,11 @@ int set_error(int code, const char* fmt, ...);
 #define NPW_HIP_CHECK(expr)                                                                   \
     do {                                                                                      \
         hipError_t _e = (expr);                                                               \
-        if (_e != hipSuccess)                                                                 \
+        if (_e != hipSuccess) {                                                               \
+            (void)hipGetLastError(); /* reported here: must not resurface at a later launch check */ \
             return ::npw::set_error(NPW_ERR_HIP, "%s failed: %s (%s:%d)", #expr,              \
                                     hipGetErrorString(_e), __FILE__, __LINE__);               \
+        }                                                                                     \
     } while (0)
 
 #define NPW_LAUNCH_CHECK()                                                                    \

@@ -403,6 +403,24 @@ fast_qr_triangular = _qr_factor_triangular
 qr_factor_triangular._npw_latency_bound = True
 
 
+def _qr_factor_triangular_batch(be, stream, arg_lists, kwargs_list):
+    """Independent qr_factor_triangular tasks (the nodes of one level of the QR tree, reference algs.py:182-234) as one
+    batched factorisation; same outputs as _qr_factor_triangular for each."""
+    for x0, x1 in arg_lists:
+        n = x0.shape[-1]
+        if tuple(x0.shape) != (n, n) or tuple(x1.shape) != (n, n):
+            raise NotImplementedError(f"qr_factor_triangular of {x0.shape} over {x1.shape}: only square tiles of equal size "
+                                      "(all the QR tree produces) are supported")
+    stacked = [be.vstack([be.tri(x0, "U", False, stream), be.tri(x1, "U", False, stream)], stream) for x0, x1 in arg_lists]
+    out = []
+    for (x0, x1), (_, T, R) in zip(arg_lists, be.geqrt_batched(stacked, stream)):
+        out.append((be.tri(x1, "L", True, stream), be.blockdiag_rows(T, min(x0.shape[-1], 32), stream), R))
+    return out
+
+
+qr_factor_triangular._npw_batch = _qr_factor_triangular_batch
+
+
 def banded_to_bidiagonal(x):
     raise NotImplementedError("banded_to_bidiagonal (LAPACK dgbbrd; reference kernels.py:43-65) is not used by "
                               "alg_wrappers and has no HIP implementation yet")

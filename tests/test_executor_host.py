@@ -127,7 +127,7 @@ def test_tsqr(tag, b, oracle_backend):
 
 
 def test_tsqr_leaves_and_tree_levels_run_as_batches(oracle_backend):
-    """Ready qr_factor tasks are grouped (config executor.batch_tasks, default 8) into one batched call; the task
+    """Ready qr_factor tasks are grouped (config executor.batch_tasks, default 16) into one batched call; the task
     set, the order constraints and the results are those of the one-by-one run."""
     Xh = ALG["tsqr_64_8/X"]
     outs = {}

@@ -27,10 +27,13 @@ from numpywren_amd.matrix import BigMatrix  # noqa: E402
 
 
 STREAMS = 1
+BATCH = None
 
 
 def run(program, reclaim=True):
     program.config["executor"]["reclaim_intermediates"] = reclaim
+    if BATCH is not None:
+        program.config["executor"]["batch_tasks"] = BATCH
     program.start()
     job_runner.lambdapack_run(program, timeout=3600, pipeline_width=STREAMS)
     if program.program_status() != lp.PS.SUCCESS:
@@ -69,9 +72,11 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=1, help="HIP streams of the executor (pipeline_width)")
+    ap.add_argument("--batch", type=int, default=None, help="executor.batch_tasks (ready tasks per batched launch)")
     a = ap.parse_args()
-    global STREAMS
+    global STREAMS, BATCH
     STREAMS = a.streams
+    BATCH = a.batch
     os.environ.setdefault("NUMPYWREN_AMD_STREAMS", str(max(4, a.streams)))
     be = get_backend()
     b = a.tile
@@ -114,7 +119,7 @@ def main():
         flops = 2 * m * b * b - 2 * b ** 3 / 3
         print(json.dumps({"what": f"{m} x {b} fp64 TSQR (alg_wrappers.tsqr), {a.leaves} leaves, {2 * a.leaves - 1} tasks",
                           "ms": round(dt * 1e3, 2), "TFLOP/s(2mn^2-2n^3/3)": round(flops / dt / 1e12, 3),
-                          "rel_err_RtR": float(err), "streams": a.streams}))
+                          "rel_err_RtR": float(err), "streams": a.streams, "batch_tasks": a.batch or 16}))
     elif a.what == "spill":
         from numpywren_amd import matrix
         # 1. the copies themselves: one tile out to pinned memory and back, on the spill stream
