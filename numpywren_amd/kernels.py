@@ -258,6 +258,17 @@ lq_factor = _lq_factor
 lq_factor.flops = _qr_flops
 
 
+def _lq_factor_batch(be, stream, arg_lists, kwargs_list):
+    """Independent lq_factor tasks (the leaves / one tree level of a row sweep of BDFAC) as one batched QR of the
+    transposed blocks; same outputs as _lq_factor for each."""
+    ins = [be.vstack([be.transpose(b, stream) for b in blocks], stream) for blocks in arg_lists]
+    return [(be.transpose(V, stream), be.transpose(T, stream), be.transpose(R, stream))
+            for V, T, R in be.geqrt_batched(ins, stream)]
+
+
+lq_factor._npw_batch = _lq_factor_batch
+
+
 @_kernel
 def _qr_leaf(be, stream, V, T, S0, *args, **kwargs):
     """S0 - V^T S0, exactly as the reference writes it (kernels.py:160-164; the WY form is commented

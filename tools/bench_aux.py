@@ -4,6 +4,8 @@
     python tools/bench_aux.py gemm32  [--n 16384]       # configs[4] family: fp32 GEMM program, 4096^2 tiles
     python tools/bench_aux.py tsqr    [--leaves 16]     # configs[3] family: (leaves*4096) x 4096 fp64 TSQR
     python tools/bench_aux.py chol    [--tiles 8]       # the Cholesky DAG on a larger tile grid
+    python tools/bench_aux.py bdfac   [--tiles 4]       # alg_wrappers.bdfac (block bidiagonalisation), tiles x tiles grid
+    python tools/bench_aux.py qr      [--tiles 4]       # alg_wrappers.qr (blocked QR program)
     python tools/bench_aux.py spill   [--tiles 4] [--budget-tiles 6]   # host-DRAM tier: copy rates, budgeted Cholesky
 
 Each prints one JSON line.  Inputs are generated on the device and resident in HBM before timing;
@@ -63,7 +65,7 @@ def timed(build, steps, warmup):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["gemm32", "tsqr", "chol", "spill"])
+    ap.add_argument("what", choices=["gemm32", "tsqr", "chol", "spill", "bdfac", "qr"])
     ap.add_argument("--budget-tiles", type=int, default=6)
     ap.add_argument("--n", type=int, default=16384)
     ap.add_argument("--leaves", type=int, default=16)
@@ -120,6 +122,32 @@ def main():
         print(json.dumps({"what": f"{m} x {b} fp64 TSQR (alg_wrappers.tsqr), {a.leaves} leaves, {2 * a.leaves - 1} tasks",
                           "ms": round(dt * 1e3, 2), "TFLOP/s(2mn^2-2n^3/3)": round(flops / dt / 1e12, 3),
                           "rel_err_RtR": float(err), "streams": a.streams, "batch_tasks": a.batch or 16}))
+    elif a.what in ("bdfac", "qr"):
+        nt = a.tiles
+        n = nt * b
+        X = BigMatrix("aux_sq", shape=(n, n), shard_sizes=(b, b))
+        for i in range(nt):
+            for j in range(nt):
+                X.put_tile(be.fill_random((b, b), 13, i * b, j * b), i, j)
+        build = (lambda: alg_wrappers.bdfac(X)) if a.what == "bdfac" else (lambda: alg_wrappers.qr(X))
+        dt, meta = timed(build, a.steps, a.warmup)
+        ntasks = len(build()[0].program.tasks)
+        out = {"what": f"{n}^2 fp64 alg_wrappers.{a.what}, {b}^2 tiles ({nt} x {nt}), {ntasks} tasks", "ms": round(dt * 1e3, 2),
+               "batch_tasks": a.batch or 16, "streams": a.streams}
+        if a.what == "qr":
+            # Rs[0, 0, 0] is the R factor of the first block column's TSQR: R^T R = X0^T X0
+            Rs = meta["outputs"][0]
+            R = Rs.get_tile(0, 0, 0)
+            G = None
+            for i in range(nt):
+                t = X.get_tile(i, 0)
+                G = be.gemm(t, t, True, False, alpha=1.0, beta=1.0 if G else 0.0, C=G)
+            D = be.gemm(R, R, True, False, alpha=1.0, beta=-1.0, C=G)
+            out["rel_err_R00"] = float(np.sqrt(be.sumsq(D) / be.sumsq(G)))
+            out["TFLOP/s(4n^3/3)"] = round(4 * n ** 3 / 3 / dt / 1e12, 2)
+        else:
+            out["TFLOP/s(8n^3/3)"] = round(8 * n ** 3 / 3 / dt / 1e12, 2)
+        print(json.dumps(out))
     elif a.what == "spill":
         from numpywren_amd import matrix
         # 1. the copies themselves: one tile out to pinned memory and back, on the spill stream
