@@ -196,6 +196,19 @@ int npw_dgeqrt_batched(int count, int64_t m, int64_t n, const double* const* A, 
                        int64_t stride_t, double* R, int64_t ldr, int64_t stride_r,
                        void* workspace, npw_stream_t stream);
 
+/* QR of two stacked n x n UPPER TRIANGULAR blocks [A1[z]; A2[z]] (what a TSQR tree node factors:
+ * the R factors of its children; LAPACK's DTPQRT with l = n), `count` of them in lock step.
+ * The strictly lower parts of A1, A2 must be zero (they are not read as zero, they are assumed
+ * zero).  Outputs exactly as npw_dgeqrt(2n, n, [A1; A2]) gives them -- V (2n x n) = [I; V2] with
+ * V2 upper triangular, T (n x n), R (n x n) -- for about a third of the work: reflector j only
+ * involves pivot row j and the first j + 1 rows of the lower block.
+ * A1, A2: HOST arrays of `count` device pointers.                                            */
+size_t npw_dtpqrt_batched_workspace_bytes(int count, int64_t n);
+int npw_dtpqrt_batched(int count, int64_t n, const double* const* A1, const double* const* A2,
+                       int64_t lda, double* V, int64_t ldv, int64_t stride_v, double* T, int64_t ldt,
+                       int64_t stride_t, double* R, int64_t ldr, int64_t stride_r, void* workspace,
+                       npw_stream_t stream);
+
 /* out = sum_i in[i]   (count operands of rows x cols each; fp64 accumulate/output).
  * in_is_f32[i] != 0 marks a float32 operand (the reference's add_matrices always
  * produces float64: np.zeros(args[0].shape) += a).  in pointers are HOST arrays of

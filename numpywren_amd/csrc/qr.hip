@@ -83,7 +83,8 @@ __device__ inline void ld_slots4(const slot_t* p0, const slot_t* p1, const slot_
 __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double* W, int64_t ldw, double* Tjj, int64_t ldt,
                                                          double* Rjj, int64_t ldr, slot_t* part /* [2][G][PB] */,
                                                          slot_t* rowbuf /* [2][PB] */, unsigned long long tag0,
-                                                         int64_t sW, int64_t sT, int64_t sR, int64_t sPart, int64_t sRow) {
+                                                         int64_t sW, int64_t sT, int64_t sR, int64_t sPart, int64_t sRow,
+                                                         int split, int64_t gap) {
     constexpr int CLD = SLAB + 8;
     {   // blockIdx.y = matrix of a batch of independent factorisations (each with its own hand-off slots)
         const int64_t z = blockIdx.y;
@@ -99,9 +100,12 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
     const int G = gridDim.x;
     const int r = blockIdx.x * SLAB + tid;
     const bool live = r < mp;
+    // The panel's rows may be two segments of the matrix (two stacked triangles: the pb pivot rows, then the leading
+    // rows of the lower block): row r of the panel is row r (r < split) or r + gap of W.
+    const int64_t wrow = (int64_t)r + (r >= split ? gap : 0);
     double pk[PB], acc[PB];
 #pragma unroll
-    for (int k = 0; k < PB; ++k) pk[k] = (live && k < pb) ? W[(int64_t)r * ldw + k] : 0.0;
+    for (int k = 0; k < PB; ++k) pk[k] = (live && k < pb) ? W[wrow * ldw + k] : 0.0;
     if (blockIdx.x == 0)
         for (int i = tid; i < PB * PB; i += SLAB) Tl[i] = 0.0;
 
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
 #pragma unroll
         for (int k = 0; k < PB; ++k) {
             if (k < pb) {
-                W[(int64_t)r * ldw + k] = (r > k) ? pk[k] : (r == k ? 1.0 : 0.0);
+                W[wrow * ldw + k] = (r > k) ? pk[k] : (r == k ? 1.0 : 0.0);
                 if (r < pb) Rjj[(int64_t)r * ldr + k] = (r <= k) ? pk[k] : 0.0;
             }
         }
@@ -394,12 +398,61 @@ int apply_panel(const Batch& b, const double* Wp, int64_t ldv, int64_t mp, int64
     return NPW_OK;
 }
 
+// Rd = Wtop - X2 for the top `rows` rows of the updated columns (final rows of R), Wtop cleared: the structured
+// update's counterpart of move_rows_kernel (the reflectors' top part is the identity, so the top rows change by -X2).
+__global__ void move_rows_sub_kernel(int rows, int64_t cols, double* W, int64_t ldw, int64_t sW, const double* X2, int64_t ldx,
+                                     int64_t sX, double* Rd, int64_t ldr, int64_t sR) {
+    W += (int64_t)blockIdx.z * sW;
+    X2 += (int64_t)blockIdx.z * sX;
+    Rd += (int64_t)blockIdx.z * sR;
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+        Rd[(int64_t)r * ldr + c] = W[(int64_t)r * ldw + c] - X2[(int64_t)r * ldx + c];
+        W[(int64_t)r * ldw + c] = 0.0;
+    }
+}
+
+// The same update for two stacked upper triangles.  The pb reflectors are [I; Vbot] with Vbot = the first `rows`
+// rows of the lower block (everything below is zero), so
+//   X1 = Wtop + Vbot^T Wbot,   X2 = T_p^T X1,   Wbot -= Vbot X2,   R rows = Wtop - X2 (Wtop cleared).
+int apply_tri(const Batch& b, const double* Vbot, int64_t ldv, int64_t rows, int64_t pb, const double* Tjj, int64_t ldt,
+              double* Wtop, double* Wbot, int64_t nc, double* X1, int64_t sX1, double* X2, int64_t sX2, double* skws,
+              size_t skcap, double* Rdst, int64_t ldr, hipStream_t s) {
+    GemmOpts g1 = batched(b, b.sV, b.sV, b.sV, sX1);
+    int64_t want = 512 / (ceil_div(nc, 64) * b.count > 0 ? ceil_div(nc, 64) * b.count : 1);
+    if (want > rows / 256) want = rows / 256;
+    if (want > 32) want = 32;
+    if (skws != nullptr && want > 1 && (size_t)want * pb * nc <= skcap) {
+        g1.splitk = (int)want;
+        g1.splitk_ws = skws;
+    }
+    int rc = gemm<double>('T', 'N', pb, nc, rows, 1.0, Vbot, ldv, Wbot, ldv, 1.0, Wtop, ldv, X1, nc, g1, s);
+    if (rc) return rc;
+    rc = gemm<double>('T', 'N', pb, nc, pb, 1.0, Tjj, ldt, X1, nc, 0.0, nullptr, 0, X2, nc, batched(b, b.sT, sX1, 0, sX2), s);
+    if (rc) return rc;
+    rc = gemm<double>('N', 'N', rows, nc, pb, -1.0, Vbot, ldv, X2, nc, 1.0, Wbot, ldv, Wbot, ldv,
+                      batched(b, b.sV, sX2, b.sV, b.sV), s);
+    if (rc) return rc;
+    const unsigned gy = (unsigned)(pb < 32 ? pb : 32);
+    hipLaunchKernelGGL(move_rows_sub_kernel, dim3((unsigned)ceil_div(nc, 256), gy, (unsigned)b.count), dim3(256), 0, s, (int)pb,
+                       nc, Wtop, ldv, b.sV, X2, nc, sX2, Rdst, ldr, b.sR);
+    NPW_LAUNCH_CHECK();
+    return NPW_OK;
+}
+
 // `b.count` independent m x n (m >= n) factorisations in lock step; the working copies are already in V, T and R are
 // cleared.  One sequence of launches serves the whole batch: the panel kernel runs count x slabs workgroups, every
 // GEMM is a strided batch.
-int geqrt_core(const Batch& b, int64_t m, int64_t n, double* V, int64_t ldv, double* T, int64_t ldt, double* R,
+//
+// tri: the matrices are two stacked n x n upper triangles (m == 2 n; LAPACK's DTPQRT with l = n).  Reflector j is then
+// e_j on top of a vector with j + 1 leading non-zeros in the lower block: a panel at column j0 only touches its pb
+// pivot rows and the first j0 + pb rows of the lower block, and the result is V = [I; V2] with V2 upper triangular --
+// the same V, T, R as the dense algorithm gives, for about a third of the work.
+int geqrt_core(const Batch& b, int64_t m, int64_t n, bool tri, double* V, int64_t ldv, double* T, int64_t ldt, double* R,
                int64_t ldr, void* workspace, hipStream_t s) {
     const QrWorkspace q = carve(workspace, m, n, b.count);
+    double* const Vlow = V + n * ldv;  // tri: the lower block
 
     // sequence tags of the panel kernel's hand-off slots: unique per call (process-wide counter seeded from the
     // clock), panel and column, so that stale slots in a recycled workspace can never look current
@@ -422,21 +475,23 @@ int geqrt_core(const Batch& b, int64_t m, int64_t n, double* V, int64_t ldv, dou
         const int64_t near_end = (b0 + ob + OB < n) ? b0 + ob + OB : n;  // end of the next block
         for (int64_t j0 = b0; j0 < b0 + ob; j0 += PB) {
             const int64_t pb = (b0 + ob - j0 < PB) ? b0 + ob - j0 : PB;
-            const int64_t mp = m - j0;
+            const int64_t mp = tri ? pb + (j0 + pb) : m - j0;   // tri: pivot rows + the leading rows of the lower block
             double* Wp = V + j0 * ldv + j0;
             const int G = (int)ceil_div(mp, SLAB);
             hipLaunchKernelGGL(qr_panel3_kernel, dim3(G, b.count), dim3(SLAB), 0, s, (int)mp, (int)pb, Wp, ldv,
                                T + j0 * ldt + j0, ldt, R + j0 * ldr + j0, ldr, reinterpret_cast<slot_t*>(q.Part),
                                reinterpret_cast<slot_t*>(q.RowBuf), call_tag + (unsigned long long)(j0 / PB) * 64, b.sV, b.sT,
-                               b.sR, q.sPart / 2, q.sRow / 2);
+                               b.sR, q.sPart / 2, q.sRow / 2, tri ? (int)pb : (int)mp, tri ? n - j0 - pb : (int64_t)0);
             NPW_LAUNCH_CHECK();
             const int64_t nc = near_end - j0 - pb;
             if (nc > 0) {
                 // the next block's columns were last written by the side stream (far update of the previous block):
                 // waiting here, not before the panel kernel, gives that update one panel time of slack
                 if (j0 == b0 && b0 > 0 && near_end > b0 + ob) NPW_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
-                int rc = apply_panel(b, Wp, ldv, mp, pb, T + j0 * ldt + j0, ldt, Wp + pb, nc, q.XnA, q.sXn, q.XnB, q.sXn,
-                                     q.XnS, (size_t)q.sXnS, R + j0 * ldr + j0 + pb, ldr, s);
+                int rc = tri ? apply_tri(b, Vlow + j0, ldv, j0 + pb, pb, T + j0 * ldt + j0, ldt, Wp + pb, Vlow + j0 + pb, nc, q.XnA,
+                                         q.sXn, q.XnB, q.sXn, q.XnS, (size_t)q.sXnS, R + j0 * ldr + j0 + pb, ldr, s)
+                             : apply_panel(b, Wp, ldv, mp, pb, T + j0 * ldt + j0, ldt, Wp + pb, nc, q.XnA, q.sXn, q.XnB, q.sXn,
+                                           q.XnS, (size_t)q.sXnS, R + j0 * ldr + j0 + pb, ldr, s);
                 if (rc) return rc;
             }
         }
@@ -445,8 +500,10 @@ int geqrt_core(const Batch& b, int64_t m, int64_t n, double* V, int64_t ldv, dou
             // block reflector on the side stream: T_b from the Gram matrix of the block's columns, then the far update
             NPW_HIP_CHECK(hipEventRecord(side->fork, s));
             NPW_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
-            const int64_t mb = m - b0;
-            double* Vb = V + b0 * ldv + b0;
+            // tri: the block's reflectors are [I; Vlow(0 : b0 + ob, b0 : b0 + ob)]; the identity adds nothing to the
+            // off-diagonal blocks of the Gram matrix, which are all merge_t reads
+            const int64_t mb = tri ? b0 + ob : m - b0;
+            double* Vb = tri ? Vlow + b0 : V + b0 * ldv + b0;
             if (ob > PB) {
                 GemmOpts sk = batched(b, b.sV, b.sV, 0, q.sGb);
                 int64_t want = mb / 256;
@@ -462,8 +519,10 @@ int geqrt_core(const Batch& b, int64_t m, int64_t n, double* V, int64_t ldv, dou
                 if (rc) return rc;
             }
             if (nfar > 0) {
-                int rc = apply_panel(b, Vb, ldv, mb, ob, T + b0 * ldt + b0, ldt, V + b0 * ldv + near_end, nfar, q.X1, q.sX, q.X2,
-                                     q.sX, q.G, (size_t)q.sG, R + b0 * ldr + near_end, ldr, side->stream);
+                int rc = tri ? apply_tri(b, Vb, ldv, mb, ob, T + b0 * ldt + b0, ldt, V + b0 * ldv + near_end, Vlow + near_end, nfar,
+                                         q.X1, q.sX, q.X2, q.sX, q.G, (size_t)q.sG, R + b0 * ldr + near_end, ldr, side->stream)
+                             : apply_panel(b, Vb, ldv, mb, ob, T + b0 * ldt + b0, ldt, V + b0 * ldv + near_end, nfar, q.X1, q.sX,
+                                           q.X2, q.sX, q.G, (size_t)q.sG, R + b0 * ldr + near_end, ldr, side->stream);
                 if (rc) return rc;
             }
             NPW_HIP_CHECK(hipEventRecord(side->join, side->stream));
@@ -476,8 +535,14 @@ int geqrt_core(const Batch& b, int64_t m, int64_t n, double* V, int64_t ldv, dou
         //  a sixth of the full product for a square matrix)
         GemmOpts gg = batched(b, b.sV, b.sV, 0, q.sG);
         gg.lower_only = true;
-        gg.k_from_diag = true;
-        int rc = gemm<double>('T', 'N', n, n, m, 1.0, V, ldv, V, ldv, 0.0, nullptr, 0, q.G, n, gg, s);
+        int rc;
+        if (tri) {  // V^T V = I + V2^T V2 with V2 upper triangular: column tile j0 only sums over rows < j0 + tile
+            gg.b_lower_tri = true;
+            rc = gemm<double>('T', 'N', n, n, n, 1.0, Vlow, ldv, Vlow, ldv, 0.0, nullptr, 0, q.G, n, gg, s);
+        } else {
+            gg.k_from_diag = true;
+            rc = gemm<double>('T', 'N', n, n, m, 1.0, V, ldv, V, ldv, 0.0, nullptr, 0, q.G, n, gg, s);
+        }
         if (rc) return rc;
         rc = merge_t(b, 0, n, OB, T, ldt, q.G, n, q.sG, 0, q.Tmp, q.sTmp, s);
         if (rc) return rc;
@@ -532,7 +597,7 @@ int npw_dgeqrt(int64_t m, int64_t n, const double* A, int64_t lda, double* V, in
     NPW_HIP_CHECK(hipMemcpy2DAsync(V, ldv * 8, A, lda * 8, n * 8, m, hipMemcpyDeviceToDevice, s));
     NPW_HIP_CHECK(hipMemset2DAsync(T, ldt * 8, 0, n * 8, n, s));
     NPW_HIP_CHECK(hipMemset2DAsync(R, ldr * 8, 0, n * 8, n, s));
-    return geqrt_core(Batch(), m, n, V, ldv, T, ldt, R, ldr, workspace, s);
+    return geqrt_core(Batch(), m, n, false, V, ldv, T, ldt, R, ldr, workspace, s);
 }
 
 size_t npw_dgeqrt_batched_workspace_bytes(int count, int64_t m, int64_t n) {
@@ -571,7 +636,38 @@ int npw_dgeqrt_batched(int count, int64_t m, int64_t n, const double* const* A, 
     b.sV = stride_v;
     b.sT = stride_t;
     b.sR = stride_r;
-    return geqrt_core(b, m, n, V, ldv, T, ldt, R, ldr, workspace, s);
+    return geqrt_core(b, m, n, false, V, ldv, T, ldt, R, ldr, workspace, s);
+}
+
+size_t npw_dtpqrt_batched_workspace_bytes(int count, int64_t n) {
+    return npw_dgeqrt_batched_workspace_bytes(count, 2 * n, n);
+}
+
+int npw_dtpqrt_batched(int count, int64_t n, const double* const* A1, const double* const* A2, int64_t lda, double* V,
+                       int64_t ldv, int64_t stride_v, double* T, int64_t ldt, int64_t stride_t, double* R, int64_t ldr,
+                       int64_t stride_r, void* workspace, npw_stream_t stream) {
+    NPW_REQUIRE(count >= 0 && n >= 0, "npw_dtpqrt_batched: negative argument");
+    if (count == 0 || n == 0) return NPW_OK;
+    NPW_REQUIRE(count <= 65535, "npw_dtpqrt_batched: more than 65535 matrices");
+    NPW_REQUIRE(A1 && A2 && V && T && R && workspace, "npw_dtpqrt_batched: NULL argument");
+    NPW_REQUIRE(lda >= n && ldv >= n && ldt >= n && ldr >= n, "npw_dtpqrt_batched: leading dimension too small");
+    NPW_REQUIRE(stride_v >= 2 * n * ldv && stride_t >= n * ldt && stride_r >= n * ldr, "npw_dtpqrt_batched: stride too small");
+    NPW_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "npw_dtpqrt_batched: workspace not 16B aligned");
+    hipStream_t s = as_stream(stream);
+    for (int z = 0; z < count; ++z) {
+        NPW_REQUIRE(A1[z] != nullptr && A2[z] != nullptr, "npw_dtpqrt_batched: A[%d] is NULL", z);
+        double* Vz = V + (int64_t)z * stride_v;
+        NPW_HIP_CHECK(hipMemcpy2DAsync(Vz, ldv * 8, A1[z], lda * 8, n * 8, n, hipMemcpyDeviceToDevice, s));
+        NPW_HIP_CHECK(hipMemcpy2DAsync(Vz + n * ldv, ldv * 8, A2[z], lda * 8, n * 8, n, hipMemcpyDeviceToDevice, s));
+        NPW_HIP_CHECK(hipMemset2DAsync(T + (int64_t)z * stride_t, ldt * 8, 0, n * 8, n, s));
+        NPW_HIP_CHECK(hipMemset2DAsync(R + (int64_t)z * stride_r, ldr * 8, 0, n * 8, n, s));
+    }
+    Batch b;
+    b.count = count;
+    b.sV = stride_v;
+    b.sT = stride_t;
+    b.sR = stride_r;
+    return geqrt_core(b, 2 * n, n, true, V, ldv, T, ldt, R, ldr, workspace, s);
 }
 
 }  // extern "C"

@@ -129,7 +129,7 @@ class _Ready(tuple):
 
 class DeviceTile(object):
     """One tile resident in HBM: a C-contiguous array of `shape`/`dtype` inside a DeviceBuffer."""
-    __slots__ = ("buf", "shape", "dtype", "offset", "ready", "zero_flag", "shared", "__weakref__")
+    __slots__ = ("buf", "shape", "dtype", "offset", "ready", "zero_flag", "shared", "upper", "__weakref__")
 
     def __init__(self, buf, shape, dtype, offset=0):
         self.buf = buf
@@ -139,6 +139,7 @@ class DeviceTile(object):
         self.ready = None       # (event_handle, stream_handle) of the producing kernel
         self.zero_flag = None   # DeviceBuffer holding the cached np.allclose(tile, 0) flag (int32)
         self.shared = False     # True for cached constant tiles that must never be written in place
+        self.upper = False      # True for a square tile known to be upper triangular with exact zeros below (an R factor)
 
     @property
     def ptr(self):
@@ -172,6 +173,7 @@ class DeviceTile(object):
         t.ready = self.ready
         t.zero_flag = self.zero_flag
         t.shared = self.shared
+        t.upper = self.upper and shape == self.shape
         return t
 
     def __repr__(self):
@@ -911,6 +913,7 @@ class HipBackend(object):
         self._use(sh, A, V, T, R)
         _ffi.check(self.lib.npw_dgeqrt(m, n, A.ptr, n, V.ptr, k, T.ptr, k, R.ptr, n, ws.ptr, sh), "geqrt")
         self._produced(sh, V, T, R)
+        R.upper = (k == n)
         return V, T, R
 
     def geqrt_batched(self, As, stream=None):
@@ -936,6 +939,36 @@ class HipBackend(object):
         out = [(DeviceTile(Vbuf, (m, n), _F64, z * vb), DeviceTile(Tbuf, (n, n), _F64, z * tb),
                 DeviceTile(Rbuf, (n, n), _F64, z * rb)) for z in range(count)]
         self._produced(sh, *[t for triple in out for t in triple])
+        for _, _, r in out:
+            r.upper = True
+        return out
+
+    def tpqrt_batched(self, pairs, stream=None):
+        """QR of [x0; x1] for pairs of n x n UPPER TRIANGULAR tiles (npw_dtpqrt_batched; what a TSQR tree node does with
+        its children's R factors): [(V 2n x n, T, R), ...] as `geqrt(vstack(x0, x1))` returns them, for a third of the
+        work.  The caller vouches for the zeros below the diagonals (tiles flagged `upper`, or `tri(x, "U")` copies)."""
+        sh = self._sh(stream)
+        pairs = [(self.as_f64(a, sh), self.as_f64(c, sh)) for a, c in pairs]
+        n = pairs[0][0].shape[0]
+        for a, c in pairs:
+            if a.shape != (n, n) or c.shape != (n, n):
+                raise ValueError(f"tpqrt: expected pairs of {n} x {n} tiles, got {a.shape} over {c.shape}")
+        count = len(pairs)
+        vb, tb = 2 * n * n * 8, n * n * 8
+        Vbuf, Tbuf, Rbuf = self.alloc(count * vb), self.alloc(count * tb), self.alloc(count * tb)
+        ws = self.alloc(max(16, self.lib.npw_dtpqrt_batched_workspace_bytes(count, n)))
+        self._use(sh, *[t for p in pairs for t in p])
+        for b in (Vbuf, Tbuf, Rbuf, ws):
+            b.streams.add(sh)
+        p1 = (ctypes.c_void_p * count)(*[a.ptr for a, _ in pairs])
+        p2 = (ctypes.c_void_p * count)(*[c.ptr for _, c in pairs])
+        _ffi.check(self.lib.npw_dtpqrt_batched(count, n, p1, p2, n, Vbuf.ptr, n, 2 * n * n, Tbuf.ptr, n, n * n, Rbuf.ptr, n, n * n,
+                                               ws.ptr, sh), "tpqrt_batched")
+        out = [(DeviceTile(Vbuf, (2 * n, n), _F64, z * vb), DeviceTile(Tbuf, (n, n), _F64, z * tb),
+                DeviceTile(Rbuf, (n, n), _F64, z * tb)) for z in range(count)]
+        self._produced(sh, *[t for triple in out for t in triple])
+        for _, _, r in out:
+            r.upper = True
         return out
 
     def tri(self, tile, uplo, unit_diag=False, stream=None):

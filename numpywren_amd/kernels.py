@@ -215,8 +215,17 @@ def _qr_factor(be, stream, *blocks, **kwargs):
     """QR of vstack(blocks): (V unit-lower-trapezoid m x n, T n x n upper with Q = I - V T V^T,
     R n x n upper) -- reference kernels.py:127-130 -> fast_qr 86-105 (LAPACK dgeqrt3).  A stack with more columns
     than rows (fast_qr hands it to slow_qr, 94-95 -> 67-84) gives V m x m, T m x m and R m x n."""
+    if _stacked_triangles(blocks):
+        return be.tpqrt_batched([tuple(blocks)], stream)[0]
     ins = be.vstack(list(blocks), stream)
     return be.geqrt(ins, stream)
+
+
+def _stacked_triangles(blocks):
+    """Two square tiles of one size, both known to be upper triangular with exact zeros below the diagonal (R factors
+    this backend produced): the node of a TSQR tree.  Then the structured factorisation applies."""
+    return (len(blocks) == 2 and all(getattr(b, "upper", False) for b in blocks) and blocks[0].shape == blocks[1].shape
+            and len(blocks[0].shape) == 2 and blocks[0].shape[0] == blocks[0].shape[1])
 
 
 qr_factor = _qr_factor
@@ -227,8 +236,17 @@ def _qr_factor_batch(be, stream, arg_lists, kwargs_list):
     """Several independent qr_factor tasks as one batched launch sequence (npw_dgeqrt_batched): the TSQR leaves and
     the nodes of one tree level (reference algs.py:30-36) are independent and latency-bound one by one.
     arg_lists[i] are the block tiles of task i; returns [(V, T, R), ...] in the same order."""
-    ins = [be.vstack(list(blocks), stream) for blocks in arg_lists]
-    return be.geqrt_batched(ins, stream)
+    out = [None] * len(arg_lists)
+    tri = [i for i, blocks in enumerate(arg_lists) if _stacked_triangles(blocks)]
+    if tri and len({arg_lists[i][0].shape for i in tri}) == 1:
+        for i, res in zip(tri, be.tpqrt_batched([tuple(arg_lists[i]) for i in tri], stream)):
+            out[i] = res
+    rest = [i for i in range(len(arg_lists)) if out[i] is None]
+    if rest:
+        ins = [be.vstack(list(arg_lists[i]), stream) for i in rest]
+        for i, res in zip(rest, be.geqrt_batched(ins, stream)):
+            out[i] = res
+    return out
 
 
 qr_factor._npw_batch = _qr_factor_batch
@@ -402,8 +420,7 @@ def _qr_factor_triangular(be, stream, x0, x1, **kwargs):
     if tuple(x0.shape) != (n, n) or tuple(x1.shape) != (n, n):
         raise NotImplementedError(f"qr_factor_triangular of {x0.shape} over {x1.shape}: only square tiles of equal size "
                                   "(all the QR tree produces) are supported")
-    stacked = be.vstack([be.tri(x0, "U", False, stream), be.tri(x1, "U", False, stream)], stream)
-    _, T, R = be.geqrt(stacked, stream)
+    _, T, R = be.tpqrt_batched([(be.tri(x0, "U", False, stream), be.tri(x1, "U", False, stream))], stream)[0]
     v = be.tri(x1, "L", True, stream)
     t = be.blockdiag_rows(T, min(n, 32), stream)
     return v, t, R
@@ -422,9 +439,11 @@ def _qr_factor_triangular_batch(be, stream, arg_lists, kwargs_list):
         if tuple(x0.shape) != (n, n) or tuple(x1.shape) != (n, n):
             raise NotImplementedError(f"qr_factor_triangular of {x0.shape} over {x1.shape}: only square tiles of equal size "
                                       "(all the QR tree produces) are supported")
-    stacked = [be.vstack([be.tri(x0, "U", False, stream), be.tri(x1, "U", False, stream)], stream) for x0, x1 in arg_lists]
+    if len({tuple(x0.shape) for x0, _ in arg_lists}) != 1:
+        return [_qr_factor_triangular(x0, x1) for x0, x1 in arg_lists]
+    stacked = [(be.tri(x0, "U", False, stream), be.tri(x1, "U", False, stream)) for x0, x1 in arg_lists]
     out = []
-    for (x0, x1), (_, T, R) in zip(arg_lists, be.geqrt_batched(stacked, stream)):
+    for (x0, x1), (_, T, R) in zip(arg_lists, be.tpqrt_batched(stacked, stream)):
         out.append((be.tri(x1, "L", True, stream), be.blockdiag_rows(T, min(x0.shape[-1], 32), stream), R))
     return out
 

@@ -179,14 +179,29 @@ class OracleBackend(object):
     def geqrt(self, A, stream=None):
         self.calls.append(("geqrt", stream))
         v, t, r = oracle.fast_qr(A.array)
-        return HostTile(v), HostTile(t), HostTile(r)
+        rt = HostTile(r)
+        rt.upper = r.shape[0] == r.shape[1]
+        return HostTile(v), HostTile(t), rt
 
     def geqrt_batched(self, As, stream=None):
         self.calls.append(("geqrt_batched", len(As)))
         out = []
         for a in As:
             v, t, r = oracle.fast_qr(a.array)
-            out.append((HostTile(v), HostTile(t), HostTile(r)))
+            rt = HostTile(r)
+            rt.upper = r.shape[0] == r.shape[1]
+            out.append((HostTile(v), HostTile(t), rt))
+        return out
+
+    def tpqrt_batched(self, pairs, stream=None):
+        self.calls.append(("tpqrt_batched", len(pairs)))
+        out = []
+        for a, c in pairs:
+            assert not np.tril(a.array, -1).any() and not np.tril(c.array, -1).any()   # the caller's promise
+            v, t, r = oracle.fast_qr(np.vstack([a.array, c.array]))
+            rt = HostTile(r)
+            rt.upper = True
+            out.append((HostTile(v), HostTile(t), rt))
         return out
 
     def tri(self, tile, uplo, unit_diag=False, stream=None):

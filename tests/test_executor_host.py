@@ -142,14 +142,16 @@ def test_tsqr_leaves_and_tree_levels_run_as_batches(oracle_backend):
         assert program.program_status() == lp.PS.SUCCESS
         assert len(res["executed_messages"]) == 15            # 8 leaves + 4 + 2 + 1
         sizes = [c[1] for c in oracle_backend.calls if c[0] == "geqrt_batched"]
+        tree = [c[1] for c in oracle_backend.calls if c[0] == "tpqrt_batched"]
         singles = sum(1 for c in oracle_backend.calls if c[0] == "geqrt")
-        assert sum(sizes) + singles == 15
+        assert sum(sizes) + sum(tree) + singles == 15
+        # the leaves are dense blocks; the tree nodes stack two R factors -> the structured factorisation
         if width == 8:
-            assert sizes == [8, 4, 2] and singles == 1
+            assert sizes == [8] and tree == [4, 2, 1] and singles == 0
         elif width == 3:
-            assert max(sizes) == 3
+            assert max(sizes) == 3 and max(tree) <= 3 and sum(tree) == 7
         else:
-            assert sizes == [] and singles == 15
+            assert sizes == [] and tree == [1] * 7 and singles == 8
         R, V, T = meta["outputs"]
         outs[width] = (R.get_block(3, 0), V.get_block(3, 0), T.get_block(0, 0))
         np.testing.assert_allclose(outs[width][0], ALG["tsqr_64_8/R_final"], atol=1e-12)

@@ -236,6 +236,43 @@ def test_qr_batched_equals_one_by_one(m, n, count):
     assert mixed[0][0].shape == (m, n) and mixed[1][0].shape == (m + 8, n)
 
 
+@pytest.mark.parametrize("n,count", [(8, 1), (32, 2), (40, 3), (96, 1), (128, 4), (200, 2), (512, 3), (1024, 2)])
+def test_stacked_triangle_qr_equals_dense(n, count):
+    """npw_dtpqrt_batched (the node of a TSQR tree: two stacked R factors) against the dense factorisation of the same
+    stack and against the oracle: same V = [I; V2], T, R."""
+    be = kernels.get_backend()
+    rng = np.random.default_rng(n * 7 + count)
+    pairs = [(np.triu(rng.standard_normal((n, n))), np.triu(rng.standard_normal((n, n)))) for _ in range(count)]
+    tiles = [(be.to_device(a), be.to_device(c)) for a, c in pairs]
+    got = be.tpqrt_batched(tiles)
+    tol = 1e-11 * n
+    for (a, c), (V, T, R) in zip(pairs, got):
+        assert V.shape == (2 * n, n) and T.shape == (n, n) and R.shape == (n, n) and R.upper
+        V, T, R = be.to_host(V), be.to_host(T), be.to_host(R)
+        Vd, Td, Rd = (be.to_host(x) for x in be.geqrt(be.to_device(np.vstack([a, c]))))
+        np.testing.assert_allclose(V, Vd, atol=tol)
+        np.testing.assert_allclose(T, Td, atol=tol)
+        np.testing.assert_allclose(R, Rd, atol=tol * 10)
+        Vr, Tr, Rr = oracle.qr_factor(a, c)
+        np.testing.assert_allclose(V, Vr, atol=tol)
+        np.testing.assert_allclose(T, Tr, atol=tol)
+        np.testing.assert_allclose(R, Rr, atol=tol * 10)
+        # structure: identity on top of an upper triangle
+        assert np.array_equal(V[:n], np.eye(n)) and not np.tril(V[n:], -1).any()
+        assert not np.tril(T, -1).any() and not np.tril(R, -1).any()
+    # kernels.qr_factor takes the structured route only for tiles the backend itself flagged as R factors
+    Ra = be.geqrt(be.to_device(rng.standard_normal((2 * n, n))))[2]
+    Rb = be.geqrt(be.to_device(rng.standard_normal((n, n))))[2]
+    assert Ra.upper and Rb.upper
+    Vk, Tk, Rk = kernels.qr_factor(Ra, Rb)
+    Vo, To, Ro = oracle.qr_factor(be.to_host(Ra), be.to_host(Rb))
+    np.testing.assert_allclose(be.to_host(Vk), Vo, atol=tol)
+    np.testing.assert_allclose(be.to_host(Rk), Ro, atol=tol * 10)
+    plain = be.to_device(be.to_host(Ra))         # same numbers, no flag: dense route, same answer
+    assert not plain.upper
+    np.testing.assert_allclose(be.to_host(kernels.qr_factor(plain, Rb)[2]), Ro, atol=tol * 10)
+
+
 def test_qr_family_vs_oracle():
     rng = np.random.default_rng(9)
     b = 48
