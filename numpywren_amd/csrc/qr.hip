@@ -16,6 +16,7 @@
 #include "npw_internal.h"
 
 #include <atomic>
+#include <type_traits>
 #include <chrono>
 
 namespace npw {
@@ -30,6 +31,27 @@ __device__ inline double wave_sum(double v) {
 }
 
 constexpr int SLAB = 256;  // rows of the panel per workgroup
+
+// f(integral_constant<0>), f(integral_constant<1>), ... f(integral_constant<PB - 1>): a loop the compiler cannot refuse to unroll
+template <int C, typename F>
+__device__ __forceinline__ void unrolled_columns(F& f) {
+    if constexpr (C < PB) {
+        f(std::integral_constant<int, C>{});
+        unrolled_columns<C + 1>(f);
+    }
+}
+
+#ifdef NPW_QR_STAMPS  // developer timing (tools/dbg): where a column's time goes inside workgroup 0, 10 ns units
+__device__ long long qr_stamps[8];
+#define QR_STAMP(i, t0)                                                           \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                 \
+        const long long _t = wall_clock64();                                      \
+        qr_stamps[i] += _t - t0;                                                  \
+        t0 = _t;                                                                  \
+    }
+#else
+#define QR_STAMP(i, t0)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Panel kernel: ONE launch per panel, the workgroups stay resident for all pb columns: every thread keeps its row of the panel (32 values) in
@@ -94,7 +116,8 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
         part += z * sPart;
         rowbuf += z * sRow;
     }
-    __shared__ double q[PB], d[PB], hh[3], Tl[PB * PB];
+    constexpr int TLD = PB + 1;  // row stride of T in LDS (odd: the eight rows a wave reads lie in different banks)
+    __shared__ double q[PB], d[PB], hh[3], Tl[PB * TLD];
     __shared__ double cols[PB * CLD];
     const int tid = threadIdx.x;
     const int G = gridDim.x;
@@ -107,7 +130,7 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
 #pragma unroll
     for (int k = 0; k < PB; ++k) pk[k] = (live && k < pb) ? W[wrow * ldw + k] : 0.0;
     if (blockIdx.x == 0)
-        for (int i = tid; i < PB * PB; i += SLAB) Tl[i] = 0.0;
+        for (int i = tid; i < PB * TLD; i += SLAB) Tl[i] = 0.0;
 
     // partial sums of (column c)^T (every column) over this slab's rows below the pivot, published for step c
     auto publish = [&](int c) {
@@ -140,7 +163,15 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
         publish(0);
     }
 
-    for (int c = 0; c < pb; ++c) {
+#ifdef NPW_QR_STAMPS
+    long long tq = wall_clock64();
+#endif
+    // The column loop is unrolled completely: with the column index a compile-time constant every access to the
+    // thread's row (pk[], acc[]) is a plain register access -- with a run-time index each of them is a chain of
+    // 32 compare-and-select pairs, and those ~1500 instructions per column were most of the 6.5 us a column took.
+    auto column = [&](auto cc) __attribute__((always_inline)) {
+        constexpr int c = decltype(cc)::value;
+        if (c >= pb) return;
         const slot_t* pin = part + (size_t)(c & 1) * G * PB;
         const slot_t* rin = rowbuf + (size_t)(c & 1) * PB;
         const unsigned long long tag = tag0 + (unsigned)c;
@@ -177,6 +208,7 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
             if (sub == 0 && k < pb) q[k] = t;
         }
         __syncthreads();
+        QR_STAMP(0, tq)   // hand-off: publish of the previous step -> all partials and the pivot row have arrived
         if (tid == 0) {
             const double alpha = d[c], ss = q[c];
             double tau = 0.0, scale = 0.0, beta = alpha;
@@ -194,6 +226,7 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
         const double tau = hh[0], scale = hh[1], beta = hh[2];
         if (tid < pb) d[tid] = d[tid] + scale * q[tid];
         __syncthreads();
+        QR_STAMP(1, tq)   // scalar part: norm, tau, d
 
 #pragma unroll
         for (int k = 0; k < PB; ++k) acc[k] = 0.0;
@@ -232,17 +265,27 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
             }
         }
         if (blockIdx.x == 0) {
-            // DLARFT: T[0:c, c] = -tau * T[0:c, 0:c] * z,  z_k = d_k (k < c);  T[c][c] = tau
-            if (tid < c) {
-                double sacc = 0.0;
-                for (int j = tid; j < c; ++j) sacc = fma(Tl[tid * PB + j], d[j], sacc);
-                Tl[tid * PB + c] = -tau * sacc;
-            } else if (tid == c) {
-                Tl[c * PB + c] = tau;
+            // DLARFT: T[0:c, c] = -tau * T[0:c, 0:c] * z,  z_k = d_k (k < c);  T[c][c] = tau.  Eight lanes per row of T
+            // (a serial dot product per row was the longest thing in the column step: 4.3 us of 6.5)
+            const int i = tid >> 3, sub = tid & 7;
+            double sacc = 0.0;
+            if (i < c)
+                for (int j = i + sub; j < c; j += 8) sacc = fma(Tl[i * TLD + j], d[j], sacc);
+            sacc += __shfl_down(sacc, 4, 8);
+            sacc += __shfl_down(sacc, 2, 8);
+            sacc += __shfl_down(sacc, 1, 8);
+            if (sub == 0) {
+                if (i < c)
+                    Tl[i * TLD + c] = -tau * sacc;
+                else if (i == c)
+                    Tl[c * TLD + c] = tau;
             }
         }
+        QR_STAMP(2, tq)   // row update + T column
         if (c + 1 < pb) publish(c + 1);
-    }
+        QR_STAMP(3, tq)   // in-slab sums through LDS + slot stores
+    };
+    unrolled_columns<0>(column);
 
     if (live) {
 #pragma unroll
@@ -257,7 +300,7 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
         __syncthreads();
         for (int i = tid; i < pb * pb; i += SLAB) {
             const int a = i / pb, b = i - a * pb;
-            Tjj[(int64_t)a * ldt + b] = Tl[a * PB + b];
+            Tjj[(int64_t)a * ldt + b] = Tl[a * TLD + b];
         }
     }
 }
@@ -669,5 +712,16 @@ int npw_dtpqrt_batched(int count, int64_t n, const double* const* A1, const doub
     b.sR = stride_r;
     return geqrt_core(b, 2 * n, n, true, V, ldv, T, ldt, R, ldr, workspace, s);
 }
+
+#ifdef NPW_QR_STAMPS
+int npw_debug_qr_stamps(long long* out, int reset) {
+    if (out) NPW_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(qr_stamps), sizeof(long long) * 8));
+    if (reset) {
+        long long z[8] = {0};
+        NPW_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(qr_stamps), z, sizeof(z)));
+    }
+    return NPW_OK;
+}
+#endif
 
 }  // extern "C"

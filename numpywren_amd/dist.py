@@ -113,14 +113,15 @@ class Comm(object):
         hdr = np.zeros(6, dtype=np.int64)
         hdr[0] = len(tile.shape)
         hdr[1:1 + len(tile.shape)] = tile.shape
-        hdr[5] = _DTYPES.index(np.dtype(tile.dtype))
+        # dtype code + what the producer knows about the tile's structure (an R factor stays one on arrival)
+        hdr[5] = _DTYPES.index(np.dtype(tile.dtype)) + (16 if getattr(tile, "upper", False) else 0)
         self.dist.send(self.torch.from_numpy(hdr), dst)
 
     def _recv_header(self, src):
         hdr = self.torch.zeros(6, dtype=self.torch.int64)
         self.dist.recv(hdr, src)
         h = hdr.numpy()
-        return tuple(int(x) for x in h[1:1 + int(h[0])]), _DTYPES[int(h[5])]
+        return tuple(int(x) for x in h[1:1 + int(h[0])]), _DTYPES[int(h[5]) & 15], bool(int(h[5]) & 16)
 
     def send_tile(self, tile, dst):
         if len(tile.shape) > 4:
@@ -148,7 +149,7 @@ class Comm(object):
     def recv_tile(self, src):
         torch = self.torch
         be = get_backend()
-        shape, dtype = self._recv_header(src)
+        shape, dtype, upper = self._recv_header(src)
         nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
         self.bytes_received += nbytes
         if self.device_tensors:
@@ -161,11 +162,14 @@ class Comm(object):
             dbuf.streams.add(ts)
             tile = DeviceTile(dbuf, shape, dtype)
             tile.ready = (be.record_new(ts), ts)
+            tile.upper = upper
             return tile
         flat = torch.empty(max(nbytes, 1), dtype=torch.uint8)
         self.dist.recv(flat, src)
         arr = flat.numpy()[:nbytes].view(dtype).reshape(shape)
-        return be.to_device(arr)
+        tile = be.to_device(arr)
+        tile.upper = upper
+        return tile
 
 
 def init_process_group(backend=None):

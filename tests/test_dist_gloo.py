@@ -103,9 +103,11 @@ def _worker(rank, world, port, scenario, outdir):
         # the leaves of a rank went to the device as one batch
         sizes = [c[1] for c in be.calls if c[0] == "geqrt_batched"] or [sum(1 for c in be.calls if c[0] == "geqrt")]
         assert sizes and sizes[0] == 8 // world
-        # tree nodes whose operands were produced here use the structured factorisation; an R factor that arrived
-        # from another rank has lost its flag and takes the dense route
-        assert any(c[0] == "tpqrt_batched" for c in be.calls) or 8 // world == 1
+        # every tree node stacks two R factors -- also those that arrived from another rank (the flag travels in
+        # the tile header) -- and takes the structured factorisation
+        nodes = local_nodes + top
+        assert sum(c[1] for c in be.calls if c[0] == "tpqrt_batched") == nodes
+        assert sum(1 for c in be.calls if c[0] == "geqrt") == (8 // world if 8 // world == 1 else 0)
         # only R factors travel: one 8 x 8 tile per tree edge that crosses ranks
         sent = [None] * world
         comm.dist.all_gather_object(sent, res["bytes_sent"])
