@@ -537,8 +537,13 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
             inner.batch2_d = 0;
             NPW_REQUIRE(opts.batch_inner == 0, "gemm: split-K with a two-level batch is not supported");
             T* P = static_cast<T*>(opts.splitk_ws);
+            inner.splitk_keep = nullptr;
             int rc = gemm<T>(transA, transB, m, n, k, T(1), A, lda, B, ldb, T(0), nullptr, 0, P, n, inner, stream);
             if (rc) return rc;
+            if (opts.splitk_keep != nullptr) {
+                *opts.splitk_keep = nsplit;
+                return NPW_OK;
+            }
             const unsigned gx = (unsigned)(ceil_div(n, 256) > 16 ? 16 : ceil_div(n, 256));
             const unsigned gy = (unsigned)(m > 1024 ? 1024 : m);
             hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(gx, gy, (unsigned)opts.batch), dim3(256), 0, stream, nsplit, P,
@@ -546,6 +551,20 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
             NPW_LAUNCH_CHECK();
             return NPW_OK;
         }
+    }
+
+    if (opts.splitk_keep != nullptr && opts.k_chunk_ == 0) {
+        // the caller reduces the partial products itself: without a split there is exactly one, the plain product
+        NPW_REQUIRE(opts.splitk_ws != nullptr, "gemm: splitk_keep without scratch");
+        GemmOpts one = opts;
+        one.splitk_keep = nullptr;
+        one.splitk = 1;
+        one.batch_c = one.batch2_c = 0;
+        one.batch_d = m * n;
+        one.batch2_d = 0;
+        *opts.splitk_keep = 1;
+        return gemm<T>(transA, transB, m, n, k, T(1), A, lda, B, ldb, T(0), nullptr, 0, static_cast<T*>(opts.splitk_ws), n, one,
+                       stream);
     }
 
     GemmParams<T> p;

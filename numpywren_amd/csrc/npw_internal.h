@@ -52,6 +52,8 @@ struct GemmOpts {
     int tag = 0;              // 1 = tile-level trailing update (separate kernel symbol for profiling)
     int splitk = 1;           // > 1 with splitk_ws: cut k into this many chunks (skinny outputs, long k)
     void* splitk_ws = nullptr;  // splitk * m * n elements of scratch
+    int* splitk_keep = nullptr;  // non-NULL: leave the partial products in splitk_ws ([problem][split][m][n], alpha and
+                                 // beta NOT applied), store their number here and skip the reduction launch
     int k_chunk_ = 0;         // internal: k range per blockIdx.y of the partial-product launch
     bool strict_lower = false;  // with lower_only on a square output: skip the diagonal tiles as well
     int batch = 1;            // > 1: blockIdx.z walks `batch` problems, operand b at base + b * batch_x elements

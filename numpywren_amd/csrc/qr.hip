@@ -412,6 +412,39 @@ __global__ void move_rows_kernel(int rows, int64_t cols, double* W, int64_t ldw,
     }
 }
 
+// X2 = T^T (sum of the split-k partial products of V^T W  [+ C]) for pb <= PBMAX rows: the reduction of the partials and
+// the small triangular product in ONE launch (they used to be two on the panel chain's critical path).
+// One thread per column of X2; T is pb x pb upper triangular: X2[i] = sum_{l <= i} T[l][i] X1[l].
+template <int PBMAX>
+__global__ __launch_bounds__(PBMAX * 16) void reduce_tt_kernel(int pb, int64_t nc, int nsplit, const double* P, const double* C,
+                                                               int64_t ldc, int64_t sC, const double* Tjj, int64_t ldt,
+                                                               int64_t sT, double* X2, int64_t sX2) {
+    // block = 16 columns x PBMAX rows: thread (l, j) first sums the partials of X1[l][j] (fixed order), then -- through
+    // LDS -- forms X2[l][j] = sum_{i <= l} T[i][l] X1[i][j]
+    __shared__ double Ts[PBMAX * (PBMAX + 1)], X1s[PBMAX * 17];
+    const int z = blockIdx.y;
+    P += (int64_t)z * nsplit * pb * nc;
+    Tjj += (int64_t)z * sT;
+    X2 += (int64_t)z * sX2;
+    if (C) C += (int64_t)z * sC;
+    const int j = threadIdx.x & 15, l = threadIdx.x >> 4;
+    const int64_t col = (int64_t)blockIdx.x * 16 + j;
+    for (int i = threadIdx.x; i < pb * pb; i += blockDim.x) Ts[(i / pb) * (PBMAX + 1) + (i % pb)] = Tjj[(int64_t)(i / pb) * ldt + (i % pb)];
+    double a = 0.0;
+    if (l < pb && col < nc) {
+        const double* p = P + (int64_t)l * nc + col;
+        for (int sidx = 0; sidx < nsplit; ++sidx) a += p[(int64_t)sidx * pb * nc];
+        if (C) a += C[(int64_t)l * ldc + col];
+    }
+    X1s[l * 17 + j] = a;
+    __syncthreads();
+    if (l < pb && col < nc) {
+        double x = 0.0;
+        for (int i = 0; i <= l; ++i) x = fma(Ts[i * (PBMAX + 1) + l], X1s[i * 17 + j], x);
+        X2[(int64_t)l * nc + col] = x;
+    }
+}
+
 // W2 (mp x nc, ld ldv) -= V_p (T_p^T (V_p^T W2)), then its top pb rows (final rows of R) move to Rdst and are
 // zeroed in place (V is zero there).  X1, X2: pb x nc scratch per matrix (strides sX1, sX2); skws: split-K scratch of
 // skcap elements per matrix, the matrices' regions back to back.
@@ -422,16 +455,30 @@ int apply_panel(const Batch& b, const double* Wp, int64_t ldv, int64_t mp, int64
     // workgroups instead of nc/64
     GemmOpts g1 = batched(b, b.sV, b.sV, 0, sX1);
     int64_t want = 512 / (ceil_div(nc, 64) * b.count > 0 ? ceil_div(nc, 64) * b.count : 1);
-    if (want > mp / 256) want = mp / 256;
+    if (want > mp / (pb <= PB ? 64 : 256)) want = mp / (pb <= PB ? 64 : 256);  // panel-wide: latency matters, cut finer
     if (want > 32) want = 32;
     if (skws != nullptr && want > 1 && (size_t)want * pb * nc <= skcap) {
         g1.splitk = (int)want;
         g1.splitk_ws = skws;
     }
-    int rc = gemm<double>('T', 'N', pb, nc, mp, 1.0, Wp, ldv, W2, ldv, 0.0, nullptr, 0, X1, nc, g1, s);
-    if (rc) return rc;
-    rc = gemm<double>('T', 'N', pb, nc, pb, 1.0, Tjj, ldt, X1, nc, 0.0, nullptr, 0, X2, nc, batched(b, b.sT, sX1, 0, sX2), s);
-    if (rc) return rc;
+    int rc;
+    if (pb <= PB && skws != nullptr && (size_t)pb * nc <= skcap) {
+        // panel-wide reflector (on the critical path): the partial products stay in the scratch and ONE small kernel
+        // reduces them and applies T^T
+        int nsplit = 1;
+        g1.splitk_ws = skws;
+        g1.splitk_keep = &nsplit;
+        rc = gemm<double>('T', 'N', pb, nc, mp, 1.0, Wp, ldv, W2, ldv, 0.0, nullptr, 0, X1, nc, g1, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(reduce_tt_kernel<PB>, dim3((unsigned)ceil_div(nc, 16), (unsigned)b.count), dim3(PB * 16), 0, s, (int)pb, nc,
+                           nsplit, skws, (const double*)nullptr, (int64_t)0, (int64_t)0, Tjj, ldt, b.sT, X2, sX2);
+        NPW_LAUNCH_CHECK();
+    } else {
+        rc = gemm<double>('T', 'N', pb, nc, mp, 1.0, Wp, ldv, W2, ldv, 0.0, nullptr, 0, X1, nc, g1, s);
+        if (rc) return rc;
+        rc = gemm<double>('T', 'N', pb, nc, pb, 1.0, Tjj, ldt, X1, nc, 0.0, nullptr, 0, X2, nc, batched(b, b.sT, sX1, 0, sX2), s);
+        if (rc) return rc;
+    }
     rc = gemm<double>('N', 'N', mp, nc, pb, -1.0, Wp, ldv, X2, nc, 1.0, W2, ldv, W2, ldv, batched(b, b.sV, sX2, b.sV, b.sV), s);
     if (rc) return rc;
     const unsigned gy = (unsigned)(pb < 32 ? pb : 32);
@@ -464,16 +511,28 @@ int apply_tri(const Batch& b, const double* Vbot, int64_t ldv, int64_t rows, int
               size_t skcap, double* Rdst, int64_t ldr, hipStream_t s) {
     GemmOpts g1 = batched(b, b.sV, b.sV, b.sV, sX1);
     int64_t want = 512 / (ceil_div(nc, 64) * b.count > 0 ? ceil_div(nc, 64) * b.count : 1);
-    if (want > rows / 256) want = rows / 256;
+    if (want > rows / (pb <= PB ? 64 : 256)) want = rows / (pb <= PB ? 64 : 256);
     if (want > 32) want = 32;
     if (skws != nullptr && want > 1 && (size_t)want * pb * nc <= skcap) {
         g1.splitk = (int)want;
         g1.splitk_ws = skws;
     }
-    int rc = gemm<double>('T', 'N', pb, nc, rows, 1.0, Vbot, ldv, Wbot, ldv, 1.0, Wtop, ldv, X1, nc, g1, s);
-    if (rc) return rc;
-    rc = gemm<double>('T', 'N', pb, nc, pb, 1.0, Tjj, ldt, X1, nc, 0.0, nullptr, 0, X2, nc, batched(b, b.sT, sX1, 0, sX2), s);
-    if (rc) return rc;
+    int rc;
+    if (pb <= PB && skws != nullptr && (size_t)pb * nc <= skcap) {
+        int nsplit = 1;
+        g1.splitk_ws = skws;
+        g1.splitk_keep = &nsplit;
+        rc = gemm<double>('T', 'N', pb, nc, rows, 1.0, Vbot, ldv, Wbot, ldv, 0.0, nullptr, 0, X1, nc, g1, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(reduce_tt_kernel<PB>, dim3((unsigned)ceil_div(nc, 16), (unsigned)b.count), dim3(PB * 16), 0, s, (int)pb, nc,
+                           nsplit, skws, (const double*)Wtop, ldv, b.sV, Tjj, ldt, b.sT, X2, sX2);
+        NPW_LAUNCH_CHECK();
+    } else {
+        rc = gemm<double>('T', 'N', pb, nc, rows, 1.0, Vbot, ldv, Wbot, ldv, 1.0, Wtop, ldv, X1, nc, g1, s);
+        if (rc) return rc;
+        rc = gemm<double>('T', 'N', pb, nc, pb, 1.0, Tjj, ldt, X1, nc, 0.0, nullptr, 0, X2, nc, batched(b, b.sT, sX1, 0, sX2), s);
+        if (rc) return rc;
+    }
     rc = gemm<double>('N', 'N', rows, nc, pb, -1.0, Vbot, ldv, X2, nc, 1.0, Wbot, ldv, Wbot, ldv,
                       batched(b, b.sV, sX2, b.sV, b.sV), s);
     if (rc) return rc;
