@@ -44,9 +44,9 @@ __device__ __forceinline__ void unrolled_columns(F& f) {
 #ifdef NPW_QR_STAMPS  // developer timing (tools/dbg): where a column's time goes inside workgroup 0, 10 ns units
 __device__ long long qr_stamps[8];
 #define QR_STAMP(i, t0)                                                           \
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                 \
+    {                                                                             \
         const long long _t = wall_clock64();                                      \
-        qr_stamps[i] += _t - t0;                                                  \
+        qr_acc[i] += _t - t0; /* registers: a global update here would itself cost ~1 us */ \
         t0 = _t;                                                                  \
     }
 #else
@@ -117,7 +117,8 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
         rowbuf += z * sRow;
     }
     constexpr int TLD = PB + 1;  // row stride of T in LDS (odd: the eight rows a wave reads lie in different banks)
-    __shared__ double q[PB], d[PB], hh[3], Tl[PB * TLD];
+    __shared__ double q2[2][PB], d2[2][PB], rowl[PB], Tl[PB * TLD];  // q, d by column parity: the T step of column c
+                                                                     // overlaps the hand-off of column c + 1
     __shared__ double cols[PB * CLD];
     const int tid = threadIdx.x;
     const int G = gridDim.x;
@@ -131,6 +132,10 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
     for (int k = 0; k < PB; ++k) pk[k] = (live && k < pb) ? W[wrow * ldw + k] : 0.0;
     if (blockIdx.x == 0)
         for (int i = tid; i < PB * TLD; i += SLAB) Tl[i] = 0.0;
+    if (tid < 2 * PB) {  // entries beyond pb stay zero for the whole kernel (the first publish has the barrier)
+        (&q2[0][0])[tid] = 0.0;
+        (&d2[0][0])[tid] = 0.0;
+    }
 
     // partial sums of (column c)^T (every column) over this slab's rows below the pivot, published for step c
     auto publish = [&](int c) {
@@ -164,6 +169,7 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
     }
 
 #ifdef NPW_QR_STAMPS
+    long long qr_acc[4] = {0, 0, 0, 0};
     long long tq = wall_clock64();
 #endif
     // The column loop is unrolled completely: with the column index a compile-time constant every access to the
@@ -175,6 +181,8 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
         const slot_t* pin = part + (size_t)(c & 1) * G * PB;
         const slot_t* rin = rowbuf + (size_t)(c & 1) * PB;
         const unsigned long long tag = tag0 + (unsigned)c;
+        double* const q = q2[c & 1];
+        double* const d = d2[c & 1];
         {
             // 8 lanes per column gather the slab partials (fixed order: deterministic), then fold
             const int k = tid >> 3, sub = tid & 7;
@@ -209,68 +217,61 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
         }
         __syncthreads();
         QR_STAMP(0, tq)   // hand-off: publish of the previous step -> all partials and the pivot row have arrived
-        if (tid == 0) {
+        // Householder scalars: every thread computes them from the two broadcast values (a single thread + a barrier
+        // + a broadcast through LDS costs more than the redundant sqrt and divisions)
+        double tau = 0.0, scale = 0.0, beta;
+        {
             const double alpha = d[c], ss = q[c];
-            double tau = 0.0, scale = 0.0, beta = alpha;
+            beta = alpha;
             if (ss != 0.0) {
                 const double nrm = sqrt(fma(alpha, alpha, ss));
                 beta = (alpha >= 0.0) ? -nrm : nrm;
                 tau = (beta - alpha) / beta;
                 scale = 1.0 / (alpha - beta);
             }
-            hh[0] = tau;
-            hh[1] = scale;
-            hh[2] = beta;
         }
-        __syncthreads();
-        const double tau = hh[0], scale = hh[1], beta = hh[2];
-        if (tid < pb) d[tid] = d[tid] + scale * q[tid];
-        __syncthreads();
-        QR_STAMP(1, tq)   // scalar part: norm, tau, d
+        QR_STAMP(1, tq)   // scalar part: norm, tau
+        // z_k = d_k + scale * q_k (the pivot row entry plus the scaled column sum) is formed where it is used
 
-#pragma unroll
-        for (int k = 0; k < PB; ++k) acc[k] = 0.0;
         if (live && r >= c) {
-            double v = 0.0;
+            const double v = (r == c) ? 1.0 : pk[c] * scale;
+            const double tv = -tau * v;
+            // z_k = d_k + scale q_k for the columns to the right, fetched in one batch (q, d are zero beyond pb, and
+            // so are the padded columns of the row: no per-column bounds checks, which would serialise the LDS reads)
+            double z[PB];
 #pragma unroll
-            for (int k = 0; k < PB; ++k)
-                if (k == c) v = (r == c) ? 1.0 : pk[k] * scale;
+            for (int k = c + 1; k < PB; ++k) z[k] = fma(scale, q[k], d[k]);
 #pragma unroll
-            for (int k = 0; k < PB; ++k) {
-                if (k < pb) {
-                    if (k > c)
-                        pk[k] = fma(-tau * d[k], v, pk[k]);
-                    else if (k == c)
-                        pk[k] = v;
-                }
-            }
-            if (c + 1 < pb) {
-                if (r == c + 1) {
-                    slot_t* rout = rowbuf + (size_t)((c + 1) & 1) * PB;
+            for (int k = c + 1; k < PB; ++k) pk[k] = fma(z[k], tv, pk[k]);
+            pk[c] = v;
+            if (c + 1 < PB && r == c + 1) {  // the next pivot row (a lane of wave 0 in slab 0) goes out through LDS ...
 #pragma unroll
-                    for (int k = 0; k < PB; ++k) st_slot(rout + k, pk[k], tag + 1);
-                }
-                double xn = 0.0;
-#pragma unroll
-                for (int k = 0; k < PB; ++k)
-                    if (k == c + 1) xn = pk[k];
-                if (r <= c + 1) xn = 0.0;
-#pragma unroll
-                for (int k = 0; k < PB; ++k) acc[k] = xn * pk[k];
-            }
-            if (r == c) {  // the diagonal entry of R replaces the implicit 1 of v once the sums are formed
-#pragma unroll
-                for (int k = 0; k < PB; ++k)
-                    if (k == c) pk[k] = beta;
+                for (int k = 0; k < PB; ++k) rowl[k] = pk[k];
             }
         }
+        if (c + 1 < PB) {
+            // products of the next column with every column, for the rows below the next pivot (0 elsewhere: rows above
+            // hold finished R entries, rows outside the matrix hold zeros)
+            const double xn = (live && r > c + 1) ? pk[c + 1 < PB ? c + 1 : c] : 0.0;
+#pragma unroll
+            for (int k = 0; k < PB; ++k) acc[k] = xn * pk[k];
+        }
+        if (live && r == c) pk[c] = beta;  // the diagonal entry of R replaces the implicit 1 of v once the sums are formed
+        if (c + 1 < pb && blockIdx.x == 0 && tid < PB) {
+            // ... so that 32 lanes of the same wave store one slot each (LDS is in order within a wave: no barrier)
+            slot_t* rout = rowbuf + (size_t)((c + 1) & 1) * PB;
+            st_slot(rout + tid, rowl[tid], tag + 1);
+        }
+        QR_STAMP(2, tq)   // row update
+        if (c + 1 < pb) publish(c + 1);
+        QR_STAMP(3, tq)   // in-slab sums through LDS + slot stores
         if (blockIdx.x == 0) {
-            // DLARFT: T[0:c, c] = -tau * T[0:c, 0:c] * z,  z_k = d_k (k < c);  T[c][c] = tau.  Eight lanes per row of T
-            // (a serial dot product per row was the longest thing in the column step: 4.3 us of 6.5)
+            // DLARFT: T[0:c, c] = -tau * T[0:c, 0:c] * z,  T[c][c] = tau -- after the publish, while the partial sums
+            // travel.  Eight lanes per row of T.
             const int i = tid >> 3, sub = tid & 7;
             double sacc = 0.0;
             if (i < c)
-                for (int j = i + sub; j < c; j += 8) sacc = fma(Tl[i * TLD + j], d[j], sacc);
+                for (int j = i + sub; j < c; j += 8) sacc = fma(Tl[i * TLD + j], fma(scale, q[j], d[j]), sacc);
             sacc += __shfl_down(sacc, 4, 8);
             sacc += __shfl_down(sacc, 2, 8);
             sacc += __shfl_down(sacc, 1, 8);
@@ -281,11 +282,12 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
                     Tl[c * TLD + c] = tau;
             }
         }
-        QR_STAMP(2, tq)   // row update + T column
-        if (c + 1 < pb) publish(c + 1);
-        QR_STAMP(3, tq)   // in-slab sums through LDS + slot stores
     };
     unrolled_columns<0>(column);
+#ifdef NPW_QR_STAMPS
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+        for (int i = 0; i < 4; ++i) qr_stamps[i] += qr_acc[i];
+#endif
 
     if (live) {
 #pragma unroll
