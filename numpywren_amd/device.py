@@ -926,6 +926,14 @@ class HipBackend(object):
         m, n = As[0].shape
         if len(As) == 1 or m < n or any(a.shape != (m, n) for a in As):
             return [self.geqrt(a, stream) for a in As]
+        # the panel kernel's workgroups (count x 256-row slabs) wait for each other: keep a batch within what the
+        # device holds at once (2 workgroups per CU)
+        cap = max(1, (2 * self.compute_units) // ((m + 255) // 256))
+        if len(As) > cap:
+            out = []
+            for i in range(0, len(As), cap):
+                out.extend(self.geqrt_batched(As[i:i + cap], stream))
+            return out
         count = len(As)
         vb, tb, rb = m * n * 8, n * n * 8, n * n * 8
         Vbuf, Tbuf, Rbuf = self.alloc(count * vb), self.alloc(count * tb), self.alloc(count * rb)
