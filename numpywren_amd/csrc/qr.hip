@@ -447,12 +447,30 @@ __global__ __launch_bounds__(PBMAX * 16) void reduce_tt_kernel(int pb, int64_t n
     }
 }
 
+// The near updates of a whole OB-wide block leave their R rows in the working matrix (one launch less per panel on the
+// critical path); this moves them in one go: row r of the block (in the panel that ends at column pe(r)) holds final R
+// entries in the columns [pe(r), c_end).  Wb, Rb point at (row b0, column b0).
+__global__ void move_block_rows_kernel(int ob, int pbw, int64_t c_end, double* Wb, int64_t ldw, int64_t sW, double* Rb,
+                                       int64_t ldr, int64_t sR) {
+    Wb += (int64_t)blockIdx.z * sW;
+    Rb += (int64_t)blockIdx.z * sR;
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // column relative to b0
+    if (c >= c_end) return;
+    for (int r = blockIdx.y; r < ob; r += gridDim.y) {
+        const int pe = (r / pbw + 1) * pbw;  // first column right of this row's panel
+        if (c >= pe) {
+            Rb[(int64_t)r * ldr + c] = Wb[(int64_t)r * ldw + c];
+            Wb[(int64_t)r * ldw + c] = 0.0;
+        }
+    }
+}
+
 // W2 (mp x nc, ld ldv) -= V_p (T_p^T (V_p^T W2)), then its top pb rows (final rows of R) move to Rdst and are
 // zeroed in place (V is zero there).  X1, X2: pb x nc scratch per matrix (strides sX1, sX2); skws: split-K scratch of
 // skcap elements per matrix, the matrices' regions back to back.
 int apply_panel(const Batch& b, const double* Wp, int64_t ldv, int64_t mp, int64_t pb, const double* Tjj, int64_t ldt,
                 double* W2, int64_t nc, double* X1, int64_t sX1, double* X2, int64_t sX2, double* skws, size_t skcap,
-                double* Rdst, int64_t ldr, hipStream_t s) {
+                double* Rdst, int64_t ldr, hipStream_t s) {  // Rdst == nullptr: the caller moves the R rows later
     // X1 = V_p^T W2 is pb x nc with a contraction over all mp rows: split k so that the launch has a few hundred
     // workgroups instead of nc/64
     GemmOpts g1 = batched(b, b.sV, b.sV, 0, sX1);
@@ -483,6 +501,7 @@ int apply_panel(const Batch& b, const double* Wp, int64_t ldv, int64_t mp, int64
     }
     rc = gemm<double>('N', 'N', mp, nc, pb, -1.0, Wp, ldv, X2, nc, 1.0, W2, ldv, W2, ldv, batched(b, b.sV, sX2, b.sV, b.sV), s);
     if (rc) return rc;
+    if (Rdst == nullptr) return NPW_OK;
     const unsigned gy = (unsigned)(pb < 32 ? pb : 32);
     hipLaunchKernelGGL(move_rows_kernel, dim3((unsigned)ceil_div(nc, 256), gy, (unsigned)b.count), dim3(256), 0, s, (int)pb, nc,
                        W2, ldv, b.sV, Rdst, ldr, b.sR);
@@ -595,15 +614,22 @@ int geqrt_core(const Batch& b, int64_t m, int64_t n, bool tri, double* V, int64_
                 int rc = tri ? apply_tri(b, Vlow + j0, ldv, j0 + pb, pb, T + j0 * ldt + j0, ldt, Wp + pb, Vlow + j0 + pb, nc, q.XnA,
                                          q.sXn, q.XnB, q.sXn, q.XnS, (size_t)q.sXnS, R + j0 * ldr + j0 + pb, ldr, s)
                              : apply_panel(b, Wp, ldv, mp, pb, T + j0 * ldt + j0, ldt, Wp + pb, nc, q.XnA, q.sXn, q.XnB, q.sXn,
-                                           q.XnS, (size_t)q.sXnS, R + j0 * ldr + j0 + pb, ldr, s);
+                                           q.XnS, (size_t)q.sXnS, nullptr, ldr, s);   // R rows: moved per block, below
                 if (rc) return rc;
             }
         }
         const int64_t nfar = n - near_end;
-        if (ob > PB || nfar > 0) {
+        const bool move_near = !tri && near_end - b0 > PB;   // the dense near updates left R rows behind
+        if (ob > PB || nfar > 0 || move_near) {
             // block reflector on the side stream: T_b from the Gram matrix of the block's columns, then the far update
             NPW_HIP_CHECK(hipEventRecord(side->fork, s));
             NPW_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+            if (move_near) {
+                const int64_t cw = near_end - b0;
+                hipLaunchKernelGGL(move_block_rows_kernel, dim3((unsigned)ceil_div(cw, 256), 32, (unsigned)b.count), dim3(256), 0,
+                                   side->stream, (int)ob, (int)PB, cw, V + b0 * ldv + b0, ldv, b.sV, R + b0 * ldr + b0, ldr, b.sR);
+                NPW_LAUNCH_CHECK();
+            }
             // tri: the block's reflectors are [I; Vlow(0 : b0 + ob, b0 : b0 + ob)]; the identity adds nothing to the
             // off-diagonal blocks of the Gram matrix, which are all merge_t reads
             const int64_t mb = tri ? b0 + ob : m - b0;
@@ -622,16 +648,25 @@ int geqrt_core(const Batch& b, int64_t m, int64_t n, bool tri, double* V, int64_
                 rc = merge_t(b, b0, b0 + ob, PB, T, ldt, q.Gb, OB, q.sGb, b0, q.Tmp, q.sTmp, side->stream);
                 if (rc) return rc;
             }
-            if (nfar > 0) {
-                int rc = tri ? apply_tri(b, Vb, ldv, mb, ob, T + b0 * ldt + b0, ldt, V + b0 * ldv + near_end, Vlow + near_end, nfar,
-                                         q.X1, q.sX, q.X2, q.sX, q.G, (size_t)q.sG, R + b0 * ldr + near_end, ldr, side->stream)
-                             : apply_panel(b, Vb, ldv, mb, ob, T + b0 * ldt + b0, ldt, V + b0 * ldv + near_end, nfar, q.X1, q.sX,
-                                           q.X2, q.sX, q.G, (size_t)q.sG, R + b0 * ldr + near_end, ldr, side->stream);
-                if (rc) return rc;
+            // The far update in two parts: first the block after next -- the only far columns the panel chain touches
+            // during the NEXT block -- then the join event, then the rest.  The caller's stream then waits for a short
+            // chain of small launches, not for the big trailing GEMMs.
+            for (int part = 0; part < 2 && nfar > 0; ++part) {
+                const int64_t c0 = (part == 0) ? near_end : ((near_end + OB < n) ? near_end + OB : n);
+                const int64_t c1 = (part == 0) ? ((near_end + OB < n) ? near_end + OB : n) : n;
+                if (c1 > c0) {
+                    int rc = tri ? apply_tri(b, Vb, ldv, mb, ob, T + b0 * ldt + b0, ldt, V + b0 * ldv + c0, Vlow + c0, c1 - c0, q.X1,
+                                             q.sX, q.X2, q.sX, q.G, (size_t)q.sG, R + b0 * ldr + c0, ldr, side->stream)
+                                 : apply_panel(b, Vb, ldv, mb, ob, T + b0 * ldt + b0, ldt, V + b0 * ldv + c0, c1 - c0, q.X1, q.sX,
+                                               q.X2, q.sX, q.G, (size_t)q.sG, R + b0 * ldr + c0, ldr, side->stream);
+                    if (rc) return rc;
+                }
+                if (part == 0) NPW_HIP_CHECK(hipEventRecord(side->join, side->stream));
             }
-            NPW_HIP_CHECK(hipEventRecord(side->join, side->stream));
+            if (nfar <= 0) NPW_HIP_CHECK(hipEventRecord(side->join, side->stream));
         }
     }
+    NPW_HIP_CHECK(hipEventRecord(side->join, side->stream));  // everything the side stream still has in flight
     NPW_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
     if (n > OB) {
         // G = V^T V, then the off-diagonal OB-blocks of T bottom-up (the diagonal ones are final)
