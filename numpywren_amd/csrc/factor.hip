@@ -19,6 +19,9 @@
 // cond(L_jj) of the 128-wide block, not of the tile).
 #include "npw_internal.h"
 
+#include <atomic>
+#include <chrono>
+
 #include <type_traits>
 
 namespace npw {
@@ -410,8 +413,12 @@ __device__ long long* g_diag_stamps = nullptr;
 //     U_col(jb-1) -> barrier -> chol16 + panel solve (waves 0-1) -> barrier
 // the rest of the rank-16 update (waves 2-6) and the inversion of the finished diagonal sub-block
 // (wave 7) run beside the next column's factorisation (look-ahead inside the workgroup).
+typedef double pslot_fwd_t __attribute__((ext_vector_type(2)));
+__device__ inline void publish_step(const double* S, const double* Wd, int jb, int lane, pslot_fwd_t* msg, unsigned long long tag);
+__device__ inline void publish_step_l(const double* S, int jb, int lane, pslot_fwd_t* msg, unsigned long long tag);
+
 __device__ inline void diag_block(int n, double* A, int64_t lda, int32_t* info, int base, double* Winv, double* S,
-                                  bool coherent) {
+                                  bool coherent, pslot_fwd_t* msg = nullptr, unsigned long long msg_tag = 0) {
     double* Wd = S + S_ELEMS;
     int* flag = reinterpret_cast<int*>(Wd + W_ELEMS);
     const int tid = threadIdx.x;
@@ -451,6 +458,9 @@ __device__ inline void diag_block(int n, double* A, int64_t lda, int32_t* info, 
                 const bool on[1] = {true};
                 update_tiles<1>(S, jb, ib, kb, on, li, lg);
             }
+            // progressive mode: the stores of block column jb-1 (issued in the previous half step) have been
+            // acknowledged before anybody publishes message jb
+            if (msg != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             NPW_STAMP(3 + 2 * jb)
             if (wave < 2) {
@@ -472,7 +482,9 @@ __device__ inline void diag_block(int n, double* A, int64_t lda, int32_t* info, 
                     update_tiles<3>(S, jb, ib, kb, on, li, lg);
                 }
             } else {
+                if (msg != nullptr) publish_step_l(S, jb, lane, msg, msg_tag);
                 invert_diag16(S, Wd, jb, lane);
+                if (msg != nullptr) publish_step(S, Wd, jb, lane, msg, msg_tag);
             }
             if (wave >= 2) {
                 // Block column jb of the 128 x 128 block is final (L below the diagonal sub-block, zeros above it):
@@ -482,7 +494,19 @@ __device__ inline void diag_block(int n, double* A, int64_t lda, int32_t* info, 
                 const bool vec = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((lda & 1) == 0);
                 for (int r = (wave - 2) * 8 + (lane >> 3); r < n; r += 48) {
                     if (vec && cp + 1 < n) {
-                        *reinterpret_cast<double2*>(&A[(int64_t)r * lda + cp]) = *reinterpret_cast<const double2*>(&S[r * SLD + cp]);
+                        const double2 v2 = *reinterpret_cast<const double2*>(&S[r * SLD + cp]);
+                        if (msg != nullptr) {  // read by the panel workgroups during this kernel: write through
+                            pslot_fwd_t x;
+                            x[0] = v2.x;
+                            x[1] = v2.y;
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(&A[(int64_t)r * lda + cp]), "v"(x) : "memory");
+                        } else {
+                            *reinterpret_cast<double2*>(&A[(int64_t)r * lda + cp]) = v2;
+                        }
+                    } else if (msg != nullptr) {  // unaligned rows: scalar write-through stores
+                        if (cp < n) __hip_atomic_store(&A[(int64_t)r * lda + cp], S[r * SLD + cp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (cp + 1 < n)
+                            __hip_atomic_store(&A[(int64_t)r * lda + cp + 1], S[r * SLD + cp + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     } else {
                         if (cp < n) A[(int64_t)r * lda + cp] = S[r * SLD + cp];
                         if (cp + 1 < n) A[(int64_t)r * lda + cp + 1] = S[r * SLD + cp + 1];
@@ -496,8 +520,21 @@ __device__ inline void diag_block(int n, double* A, int64_t lda, int32_t* info, 
     if (failed) {
         for (int idx = tid; idx < NB * NB; idx += DIAG_THREADS)
             __hip_atomic_store(&Winv[(idx / NB) * LW + (idx % NB)], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (msg != nullptr) {
+            // the panel workgroups are waiting for messages that will not come: release them (zeros; the matrix is
+            // reported as not positive definite, its contents are unspecified)
+            for (int k = 0; k < NJB; ++k) {
+                pslot_fwd_t x;
+                x[0] = 0.0;
+                x[1] = __longlong_as_double((long long)(msg_tag + k));
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(msg + (size_t)k * 2 * JB * JB + tid), "v"(x) : "memory");
+            }
+        }
         return;
     }
+    // Progressive mode: nobody in this launch needs inv(L_jj) -- potrf_right inverts all diagonal blocks of the finished
+    // factor with ONE trtri_diag_kernel launch instead of 5.4 + 1.9 us at the end of every block column.
+    if (msg != nullptr) return;
     if (wave >= nbk && lane < JB) {  // identity padding blocks
 #pragma unroll
         for (int k = 0; k < JB; ++k) Wd[(wave * JB + k) * WLD + li] = (k == li) ? 1.0 : 0.0;
@@ -620,25 +657,170 @@ __device__ inline void panel_rows(double* S, double* P, int64_t lda, int rows, c
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Progressive hand-off (the fused kernel's default): the panel workgroups do not wait for inv(L_jj).  After step k of the
+// diagonal block's factorisation workgroup 0 publishes a MESSAGE k = { inv(D_k) (the 16 x 16 diagonal sub-block's
+// inverse), L[k, k-1] } as 512 tagged 16-byte slots ({value, tag}: arrival of the data is the synchronisation, as in
+// qr.hip), and the panel rows advance by substitution,
+//     X_k = (B_k - sum_{i<k} X_i L[k,i]^T) inv(D_k)^T,
+// one 16-column block behind the factorisation instead of a whole block inverse (5.4 us) + a 128-wide product behind
+// it.  L[k, 0..k-2] is prefetched with plain loads one step earlier: message k-1 is published after every wave of
+// workgroup 0 has seen the stores of column blocks <= k-2 acknowledged (s_waitcnt before the barrier that precedes it).
+// ------------------------------------------------------------------------------------------------
+typedef double pslot_t __attribute__((ext_vector_type(2)));  // {value, tag bits}
+constexpr int MSG_SLOTS = 2 * JB * JB;                        // inv(D_k) then L[k, k-1]
+constexpr int PGROWS = 64;                                    // rows per panel workgroup in this mode (4 computing waves)
+constexpr int LRD = NB - JB + 1;                              // row stride of the prefetched L[k, 0..k-1) rows (113)
+
+__device__ inline void st_pslot(pslot_t* p, double v, unsigned long long tag) {
+    pslot_t x;
+    x[0] = v;
+    x[1] = __longlong_as_double((long long)tag);
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+}
+__device__ inline double ld_pslot(const pslot_t* p, unsigned long long tag) {
+    for (int spin = 0; spin < (1 << 22); ++spin) {  // bounded: a lost message must not hang the GPU
+        pslot_t x;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(p) : "memory");
+        if (__double_as_longlong(x[1]) == (long long)tag) return x[0];
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return 0.0;
+}
+
+// workgroup 0, wave 7, step jb: message jb in two halves -- L[jb, jb-1] (final since the previous step) before the
+// wave inverts the diagonal sub-block, inv(D_jb) right after
+__device__ inline void publish_step_l(const double* S, int jb, int lane, pslot_t* msg, unsigned long long tag) {
+    if (jb == 0) return;
+    pslot_t* m = msg + (size_t)jb * MSG_SLOTS + JB * JB;
+    double v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = lane + 64 * i;
+        v[i] = S[(jb * JB + (e >> 4)) * SLD + (jb - 1) * JB + (e & 15)];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st_pslot(m + lane + 64 * i, v[i], tag + jb);
+}
+__device__ inline void publish_step(const double* S, const double* Wd, int jb, int lane, pslot_t* msg, unsigned long long tag) {
+    pslot_t* m = msg + (size_t)jb * MSG_SLOTS;
+    double v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = lane + 64 * i;
+        v[i] = Wd[(jb * JB + (e >> 4)) * WLD + (e & 15)];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st_pslot(m + lane + 64 * i, v[i], tag + jb);
+}
+
+__device__ inline void panel_rows_prog(double* S, double* P, int64_t lda, int rows, const double* Ldiag, const pslot_t* msg,
+                                       unsigned long long tag) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    double* Lrow = S + PGROWS * SLD;            // [2][JB][LRD]: L[k, 0 .. k-1) of the current / next step
+    double* Msg = Lrow + 2 * JB * LRD;          // [2][2][JB][WLD]: inv(D_k), L[k, k-1]
+    {
+        constexpr int PER = PGROWS * NB / DIAG_THREADS;  // 16
+        const int c = tid & (NB - 1), r0 = tid >> 7;
+        double v[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int r = r0 + (DIAG_THREADS / NB) * i;
+            v[i] = (r < rows) ? P[(int64_t)r * lda + c] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) S[(r0 + (DIAG_THREADS / NB) * i) * SLD + c] = v[i];
+    }
+    for (int k = 0; k < NJB; ++k) {
+        const int par = k & 1;
+        double* Mk = Msg + par * 2 * JB * WLD;
+        {   // one slot per thread: 256 of inv(D_k), 256 of L[k, k-1]
+            const int e = tid & (JB * JB - 1), half = tid >> 8;
+            if (half == 0 || k > 0) {
+                const double v = ld_pslot(msg + (size_t)k * MSG_SLOTS + tid, tag + k);
+                Mk[half * JB * WLD + (e >> 4) * WLD + (e & 15)] = v;
+            }
+        }
+        __syncthreads();
+#ifdef NPW_PP_DEBUG_L
+        if (k > 0 && tid >= 256) {
+            const int e = tid & 255;
+            const double g = Ldiag[(int64_t)(k * JB + (e >> 4)) * lda + (k - 1) * JB + (e & 15)];
+            const double mv = Mk[JB * WLD + (e >> 4) * WLD + (e & 15)];
+            if (blockIdx.x == 1 && k <= 2 && mv != g)
+                printf("k=%d r=%d c=%d msg=%.17g global=%.17g diff=%.3e\n", k, e >> 4, e & 15, mv, g, mv - g);
+        }
+        __syncthreads();
+#endif
+        if (wave < PGROWS / JB) {
+            const int rb = wave;
+            d4_t acc = {0, 0, 0, 0};
+            const double* Lr = Lrow + par * JB * LRD;
+            for (int i = 0; i + 1 < k; ++i) {   // prefetched blocks L[k, i], i <= k - 2
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const double a = S[(rb * JB + li) * SLD + i * JB + 4 * st + lg];
+                    const double b = Lr[li * LRD + i * JB + 4 * st + lg];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                }
+            }
+            if (k > 0) {
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const double a = S[(rb * JB + li) * SLD + (k - 1) * JB + 4 * st + lg];
+                    const double b = Mk[JB * WLD + li * WLD + 4 * st + lg];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                }
+            }
+            // T = B_k - acc, back into the strip (this wave's rows only: LDS is in order within a wave)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double* q = &S[(rb * JB + lg + 4 * r) * SLD + k * JB + li];
+                *q = *q - acc[r];
+            }
+            d4_t x = {0, 0, 0, 0};
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const double a = S[(rb * JB + li) * SLD + k * JB + 4 * st + lg];
+                const double b = Mk[li * WLD + 4 * st + lg];   // inv(D_k)[c = li][j]
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, x, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rb * JB + lg + 4 * r;
+                S[row * SLD + k * JB + li] = x[r];
+                if (row < rows) P[(int64_t)row * lda + k * JB + li] = x[r];
+            }
+        } else if (k + 1 < NJB && k > 0) {
+            // waves 4..7: L[k+1, 0 .. k) for the next step -- visible now that message k is here
+            double* Ln = Lrow + (par ^ 1) * JB * LRD;
+            const int t = tid - (PGROWS / JB) * 64;    // 0..255
+            for (int e = t; e < JB * JB * k; e += DIAG_THREADS - (PGROWS / JB) * 64) {
+                const int r = e / (JB * k), c = e - r * (JB * k);
+                Ln[r * LRD + c] = Ldiag[(int64_t)((k + 1) * JB + r) * lda + c];
+            }
+        }
+    }
+}
+
 // One block column of the right-looking factorisation in one launch: workgroup 0 = diagonal block (factor +
 // invert), workgroups 1.. = the rows below it.  All workgroups are resident at once (<= 63, one per CU; the
 // dispatcher starts workgroup 0 first), so the flag wait cannot deadlock.
 __global__ __launch_bounds__(DIAG_THREADS) void potrf_panel_kernel(int n, double* A, int64_t lda, int32_t* info, int base,
-                                                                   double* Winv, int m_below, int* ready, int ready_val) {
+                                                                   double* Winv, int m_below, pslot_t* msg,
+                                                                   unsigned long long msg_tag) {
     extern __shared__ __attribute__((aligned(16))) double S[];
     if (blockIdx.x == 0) {
-        // inv(L_jj) is written through (coherent stores); every wave waits for its own stores to be acknowledged
-        // and the barrier orders all of them before thread 0 raises the flag.  No release fence: on this multi-die part that would write
-        // back the whole dirty L2 of the XCD (tens of microseconds after a GEMM).
-        diag_block(n, A, lda, info, base, Winv, S, true);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have been acknowledged
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(ready, ready_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // factor + publish a message per 16-column step; then inv(L_jj) for the trsm tasks (nobody in this kernel waits
+        // for it)
+        diag_block(n, A, lda, info, base, Winv, S, false, msg, msg_tag);
         return;
     }
-    const int r0 = (blockIdx.x - 1) * PROWS;
+    const int r0 = (blockIdx.x - 1) * PGROWS;
     double* P = A + (int64_t)(n + r0) * lda;  // rows below the diagonal block, same columns
-    panel_rows(S, P, lda, min(PROWS, m_below - r0), Winv, ready, ready_val);
+    panel_rows_prog(S, P, lda, min(PGROWS, m_below - r0), A, msg, msg_tag);
 }
 
 // Batched inversion of the NB x NB diagonal blocks of the n x n lower-triangular L:
@@ -780,10 +962,13 @@ int trsm_rec(const TrsmCtx& c, int64_t coff, int64_t n, bool touched) {
 // once per block column: sum ~ n^3 / (3 NB) * 16 B, 1.4 GB for n = 4096) for a third of the launches;
 // a tile is latency-bound on the chain of diagonal blocks, not on flops, so fewer, wider launches win.
 int potrf_right(int64_t n, double* A, int64_t lda, int32_t* info, double* Winv, hipStream_t s) {
-    // flag of the fused panel kernel: first word of the scratch behind the inverse groups (free until
-    // complete_groups runs); the value it waits for is the block column's ordinal, so one memset per call
-    int* ready = reinterpret_cast<int*>(Winv + winv_group_elems(n));
-    NPW_HIP_CHECK(hipMemsetAsync(ready, 0, sizeof(int), s));
+    // messages of the fused panel kernel (NJB x 512 tagged slots): in the scratch behind the inverse groups, free until
+    // complete_groups runs.  The tags are unique per call (process-wide counter seeded from the clock), block column
+    // and step, so a recycled workspace can never hold a slot that looks current.
+    pslot_t* msg = reinterpret_cast<pslot_t*>(Winv + winv_group_elems(n));
+    static std::atomic<unsigned long long> call_counter{
+        (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() & 0x3fffffffULL};
+    const unsigned long long call_tag = (call_counter.fetch_add(1) + 1) << 20;
     for (int64_t j0 = 0; j0 < n; j0 += NB) {
         const int64_t nb = (n - j0 < NB) ? n - j0 : NB;
         double* Ajj = A + j0 * lda + j0;
@@ -795,9 +980,9 @@ int potrf_right(int64_t n, double* A, int64_t lda, int32_t* info, double* Winv, 
             NPW_LAUNCH_CHECK();
             if (m == 0) break;
         } else {
-            const unsigned wgs = 1 + (unsigned)ceil_div(m, PROWS);
+            const unsigned wgs = 1 + (unsigned)ceil_div(m, PGROWS);
             hipLaunchKernelGGL(potrf_panel_kernel, dim3(wgs), dim3(DIAG_THREADS), DIAG_LDS_BYTES, s, (int)nb, Ajj, lda, info,
-                               (int)j0, Wj, (int)m, ready, (int)(j0 / NB) + 1);
+                               (int)j0, Wj, (int)m, msg, call_tag + (unsigned long long)(j0 / NB) * NJB + 1);
             NPW_LAUNCH_CHECK();
         }
         double* P = A + (j0 + nb) * lda + j0;
@@ -813,6 +998,12 @@ int potrf_right(int64_t n, double* A, int64_t lda, int32_t* info, double* Winv, 
         u.lower_only = true;
         rc = gemm<double>('N', 'T', m, m, nb, -1.0, P, lda, P, lda, 1.0, A22, lda, A22, lda, u, s);
         if (rc) return rc;
+    }
+    if (n > NB) {
+        // the fused launches left the block inverses out: all of them now, from the finished factor
+        hipLaunchKernelGGL(trtri_diag_kernel, dim3((unsigned)ceil_div(n, NB)), dim3(DIAG_THREADS), DIAG_LDS_BYTES, s, (int)n, A, lda,
+                           Winv);
+        NPW_LAUNCH_CHECK();
     }
     return NPW_OK;
 }
