@@ -499,7 +499,7 @@ __device__ inline void diag_block(int n, double* A, int64_t lda, int32_t* info, 
                             pslot_fwd_t x;
                             x[0] = v2.x;
                             x[1] = v2.y;
-                            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(&A[(int64_t)r * lda + cp]), "v"(x) : "memory");
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(&A[(int64_t)r * lda + cp]), "v"(x) : "memory");
                         } else {
                             *reinterpret_cast<double2*>(&A[(int64_t)r * lda + cp]) = v2;
                         }
@@ -527,7 +527,7 @@ __device__ inline void diag_block(int n, double* A, int64_t lda, int32_t* info, 
                 pslot_fwd_t x;
                 x[0] = 0.0;
                 x[1] = __longlong_as_double((long long)(msg_tag + k));
-                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(msg + (size_t)k * 2 * JB * JB + tid), "v"(x) : "memory");
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(msg + (size_t)k * 2 * JB * JB + tid), "v"(x) : "memory");
             }
         }
         return;
@@ -672,11 +672,12 @@ constexpr int MSG_SLOTS = 2 * JB * JB;                        // inv(D_k) then L
 constexpr int PGROWS = 64;                                    // rows per panel workgroup in this mode (4 computing waves)
 constexpr int LRD = NB - JB + 1;                              // row stride of the prefetched L[k, 0..k-1) rows (113)
 
+// (s_nop after the store: see st_slot in qr.hip -- a wide store still reads its data registers after issue)
 __device__ inline void st_pslot(pslot_t* p, double v, unsigned long long tag) {
     pslot_t x;
     x[0] = v;
     x[1] = __longlong_as_double((long long)tag);
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
 }
 __device__ inline double ld_pslot(const pslot_t* p, unsigned long long tag) {
     for (int spin = 0; spin < (1 << 22); ++spin) {  // bounded: a lost message must not hang the GPU

@@ -68,11 +68,14 @@ __device__ long long qr_stamps[8];
 // synchronisation (no counter, no fence, no separate barrier; one memory hop per column instead of three).
 typedef double slot_t __attribute__((ext_vector_type(2)));  // {value, tag bits}
 
+// (The trailing s_nop: a store of more than 8 bytes keeps reading its data registers for a wait state or two after
+// issue; the compiler pads its own stores against a following VALU write of those registers but cannot see into the
+// asm -- without the padding lanes 12..15 of every 16 stored the NEXT slot's contents when stores followed each other.)
 __device__ inline void st_slot(slot_t* p, double v, unsigned long long tag) {
     slot_t x;
     x[0] = v;
     x[1] = __longlong_as_double((long long)tag);
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
 }
 // poll up to four slots until each carries `tag` (slots whose `need` flag is false are not waited for)
 __device__ inline void ld_slots4(const slot_t* p0, const slot_t* p1, const slot_t* p2, const slot_t* p3, bool n0, bool n1,

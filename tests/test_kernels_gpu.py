@@ -137,6 +137,41 @@ def test_chol_not_positive_definite():
         kernels.chol(A)
 
 
+@pytest.mark.parametrize("n", [129, 192, 257, 300, 511, 513, 640, 1000])
+def test_chol_block_column_handoff(n):
+    """Sizes with at least one fused block-column launch (diagonal block + panel rows that follow it one 16-column
+    step behind through tagged-slot messages): odd leading dimensions (scalar write-through stores), a single panel
+    row, ragged last block columns."""
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((n, n))
+    a = x @ x.T + n * np.eye(n)
+    L = kernels.chol(a)
+    ref = np.linalg.cholesky(a)
+    np.testing.assert_allclose(L, ref, atol=1e-12 * n, rtol=0)
+    assert not np.triu(L, 1).any()
+    assert np.linalg.norm(L @ L.T - a) / np.linalg.norm(a) < 1e-14
+    # the factor's cached block inverses (one launch for all of them at the end) serve the trsm consumers
+    y = rng.standard_normal((n, n))
+    np.testing.assert_allclose(kernels.trsm(L, y) @ ref.T, y, atol=1e-9 * n)
+    # bitwise repeatable: the hand-off changes when a panel row is computed, never what is computed
+    assert np.array_equal(kernels.chol(a), L)
+
+
+@pytest.mark.parametrize("n,bad", [(300, 5), (300, 140), (300, 299), (640, 128), (640, 400), (1000, 600)])
+def test_chol_failure_is_reported_from_any_block_column(n, bad):
+    """A non-positive pivot in any block column: LinAlgError, and the panel workgroups that were waiting for the
+    rest of that block column's messages are released (the call returns instead of spinning)."""
+    rng = np.random.default_rng(n + bad)
+    x = rng.standard_normal((n, n))
+    a = x @ x.T + n * np.eye(n)
+    a[bad, bad] = -1.0
+    with pytest.raises(np.linalg.LinAlgError):
+        kernels.chol(a)
+    # and the library is in a sane state afterwards
+    a[bad, bad] = 4.0 * n
+    np.testing.assert_allclose(kernels.chol(a), np.linalg.cholesky(a), atol=1e-11 * n)
+
+
 def test_zero_short_circuits():
     rng = np.random.default_rng(5)
     s, x = rng.standard_normal((32, 32)), rng.standard_normal((32, 32))
