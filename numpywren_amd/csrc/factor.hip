@@ -458,6 +458,9 @@ __device__ inline void diag_block(int n, double* A, int64_t lda, int32_t* info, 
                 const bool on[1] = {true};
                 update_tiles<1>(S, jb, ib, kb, on, li, lg);
             }
+            // wave 7 is idle in this half step: it sends the L[jb, jb-1] half of message jb now (final since the
+            // previous step; the panel workgroups act on a message only when all of it, inv(D_jb) included, is there)
+            if (wave == 7 && msg != nullptr) publish_step_l(S, jb, lane, msg, msg_tag);
             // progressive mode: the stores of block column jb-1 (issued in the previous half step) have been
             // acknowledged before anybody publishes message jb
             if (msg != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -482,7 +485,6 @@ __device__ inline void diag_block(int n, double* A, int64_t lda, int32_t* info, 
                     update_tiles<3>(S, jb, ib, kb, on, li, lg);
                 }
             } else {
-                if (msg != nullptr) publish_step_l(S, jb, lane, msg, msg_tag);
                 invert_diag16(S, Wd, jb, lane);
                 if (msg != nullptr) publish_step(S, Wd, jb, lane, msg, msg_tag);
             }
@@ -822,6 +824,9 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_panel_kernel(int n, double
     const int r0 = (blockIdx.x - 1) * PGROWS;
     double* P = A + (int64_t)(n + r0) * lda;  // rows below the diagonal block, same columns
     panel_rows_prog(S, P, lda, min(PGROWS, m_below - r0), A, msg, msg_tag);
+#ifdef NPW_DIAG_STAMPS
+    if (g_diag_stamps && threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) g_diag_stamps[24] = wall_clock64();
+#endif
 }
 
 // Batched inversion of the NB x NB diagonal blocks of the n x n lower-triangular L:
@@ -1121,6 +1126,17 @@ int npw_dpotrf_lower(int64_t n, const double* A, int64_t lda, double* Lout, int6
 }
 
 #ifdef NPW_DIAG_STAMPS
+// one fused block-column launch (progressive mode) on a (128 + m_below) x 128 panel: stamps 0..18 from workgroup 0,
+// stamp 24 = end of the last panel workgroup
+int npw_debug_fused(double* A, int64_t lda, int m_below, int32_t* info, double* Winv, void* msg, unsigned long long tag,
+                    long long* stamps) {
+    ensure_big_lds();
+    hipMemcpyToSymbol(HIP_SYMBOL(g_diag_stamps), &stamps, sizeof(stamps));
+    const unsigned wgs = 1 + (unsigned)ceil_div(m_below, PGROWS);
+    hipLaunchKernelGGL(potrf_panel_kernel, dim3(wgs), dim3(DIAG_THREADS), DIAG_LDS_BYTES, 0, 128, A, lda, info, 0, Winv, m_below,
+                       static_cast<pslot_t*>(msg), tag);
+    return hipDeviceSynchronize() == hipSuccess ? 0 : 1;
+}
 int npw_debug_diag(double* A, int64_t lda, int32_t* info, double* Winv, long long* stamps) {
     ensure_big_lds();
     hipMemcpyToSymbol(HIP_SYMBOL(g_diag_stamps), &stamps, sizeof(stamps));
