@@ -40,6 +40,19 @@ def gemm(pwex, X, Y, out_bucket=None, tasks_per_job=1, local=False, dtype=np.flo
     return XY
 
 
+def gemm_with_prefetch(X, Y, bidx0, bidx1, block_chunk_size=16):
+    """One output block (bidx0, bidx1) of X . Y as an ndarray (reference binops.py:60-105: a double-buffered S3
+    prefetch around `result += b1.dot(b2)`).  Here the operand tiles are already in HBM and the products accumulate
+    in one GPU buffer; `block_chunk_size` (the prefetch depth) has no counterpart."""
+    assert X._block_idxs(1) == Y._block_idxs(0)
+    be = get_backend()
+    acc = None
+    for r in X._block_idxs(1):
+        a, b = be.as_f64(X.get_tile(bidx0, r)), be.as_f64(Y.get_tile(r, bidx1))
+        acc = be.gemm(a, b, False, False, alpha=1.0, beta=0.0 if acc is None else 1.0, C=acc, out=acc)
+    return be.to_host(acc)
+
+
 def _stub(name):
     def f(*args, **kwargs):
         raise NotImplementedError(f"binops.{name} is not implemented (a stub in the reference as well)")
@@ -48,5 +61,6 @@ def _stub(name):
     return f
 
 
-for _n in ("add", "sub", "mul", "div", "logical_and", "logical_or", "xor", "elemwise_binop_func", "trisolve"):
+for _n in ("gemv", "syrk", "posv", "add", "sub", "mul", "div", "logical_and", "logical_or", "xor", "elemwise_binop_func",
+           "trisolve"):
     globals()[_n] = _stub(_n)

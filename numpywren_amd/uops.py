@@ -6,8 +6,8 @@ local GPU, return the factor as a BigMatrix."""
 from . import alg_wrappers, job_runner
 from . import lambdapack as lp
 
-_STUBS = ("sum", "prod", "argmin", "argmax", "min", "max", "norm", "sqrt", "neg", "abs", "sign", "ceil", "floor",
-          "round", "exp", "log", "log10", "log2", "sin", "cos", "tan")
+_STUBS = ("reshard", "sum", "prod", "argmin", "argmax", "min", "max", "norm", "sqrt", "neg", "abs", "square", "sign", "ceil",
+          "floor", "round", "exp", "log", "log10", "log2", "sin", "cos", "tan", "power", "elemwise_uop_func")
 
 
 def _make_stub(name):
