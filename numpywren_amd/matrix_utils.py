@@ -113,6 +113,26 @@ def get_col(bigm, col, workers=1, mmap_loc=None):
     return np.vstack([np.atleast_2d(bigm.get_block(i, col)) for i in bigm._block_idxs(0)])
 
 
+def get_rows(bigm, rows, workers=1, mmap_loc=None):
+    """Several block rows stacked (reference matrix_utils.py:221-232; there through /dev/shm memory maps)."""
+    assert len(bigm.shape) == 2
+    return np.vstack([get_row(bigm, r) for r in rows])
+
+
+def chunk(l, n):
+    """Yield successive n-sized chunks from l (reference matrix_utils.py:56-60)."""
+    if n == 0:
+        return []
+    for i in range(0, len(l), n):
+        yield l[i:i + n]
+
+
+def block_key_to_block(key):
+    """Object key -> ((start, end), ...) block ranges, None for the header (reference matrix_utils.py:123-139)."""
+    from .matrix import block_key_to_block as _impl
+    return _impl(key)
+
+
 def put_row(bigm, data, row, workers=1, mmap_loc=None, big_axis=0):
     assert len(bigm.shape) == 2
     for bidx, block in zip(bigm.block_idxs, bigm.blocks):

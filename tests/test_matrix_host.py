@@ -156,3 +156,26 @@ def test_rows_cols(host_store):
     assert np.all(get_col(m, 1) == X[:, 16:32])
     put_row(m, np.zeros((16, 48)), 0)
     assert not m.numpy()[:16].any()
+
+
+def test_matrix_utils_row_col_helpers(host_store):
+    """get_row / get_col / get_rows / put_row / put_col / chunk / block_key_to_block (reference matrix_utils.py)."""
+    from numpywren_amd import matrix_utils
+    rng = np.random.default_rng(4)
+    Xh = rng.standard_normal((20, 14))
+    X = BigMatrix("mu_rows", shape=Xh.shape, shard_sizes=(8, 6), write_header=True)
+    shard_matrix(X, Xh)
+    assert np.array_equal(matrix_utils.get_row(X, 1), Xh[8:16])
+    assert np.array_equal(matrix_utils.get_col(X, 2), Xh[:, 12:14])
+    assert np.array_equal(matrix_utils.get_rows(X, [0, 2]), np.vstack([Xh[0:8], Xh[16:20]]))
+    new = rng.standard_normal((8, 14))
+    matrix_utils.put_row(X, new, 0)
+    assert np.array_equal(X.numpy()[:8], new)
+    newc = rng.standard_normal((20, 6))
+    matrix_utils.put_col(X, newc, 1)
+    assert np.array_equal(X.numpy()[:, 6:12], newc)
+    assert [list(c) for c in matrix_utils.chunk(list(range(7)), 3)] == [[0, 1, 2], [3, 4, 5], [6]]
+    assert list(matrix_utils.chunk([1, 2], 0)) == []
+    key = X.__shard_idx_to_key__((2, 1))
+    assert matrix_utils.block_key_to_block(key) == ((16, 20), (6, 12))
+    assert matrix_utils.block_key_to_block(X.key_base + "/header") is None
