@@ -897,6 +897,19 @@ class HipBackend(object):
         self._produced(sh, out)
         return out
 
+    def block(self, tile, r0, r1, c0, c1, stream=None):
+        """tile[r0:r1, c0:c1] as a new tile (strided device-to-device copy)."""
+        self._require_2d(tile, "block")
+        sh = self._sh(stream)
+        out = self.empty((r1 - r0, c1 - c0), tile.dtype)
+        self._use(sh, tile, out)
+        isz = tile.dtype.itemsize
+        if out.nbytes:
+            _ffi.check(self.lib.npw_memcpy2d_d2d_async(out.ptr, (c1 - c0) * isz, tile.ptr + (r0 * tile.shape[1] + c0) * isz,
+                                                       tile.shape[1] * isz, (c1 - c0) * isz, r1 - r0, sh), "block")
+        self._produced(sh, out)
+        return out
+
     def geqrt(self, A, stream=None):
         """Householder QR of the m x n tile with k = min(m, n) reflectors: returns (V m x k unit lower trapezoid,
         T k x k, R k x n upper) -- for m >= n what the reference's fast_qr returns, for m < n its slow_qr."""

@@ -176,6 +176,9 @@ class OracleBackend(object):
     def rows(self, tile, start, stop, stream=None):
         return HostTile(tile.array[start:stop])
 
+    def block(self, tile, r0, r1, c0, c1, stream=None):
+        return HostTile(np.ascontiguousarray(tile.array[r0:r1, c0:c1]))
+
     def geqrt(self, A, stream=None):
         self.calls.append(("geqrt", stream))
         v, t, r = oracle.fast_qr(A.array)

@@ -411,3 +411,23 @@ def test_chol_trsm_ill_conditioned(log_cond):
     assert np.linalg.norm(X @ L.T - B) / (np.linalg.norm(X) * np.linalg.norm(L)) < 1e-15
     Xr = sl.solve_triangular(np.linalg.cholesky(A), B.T, lower=True).T
     assert np.linalg.norm(X - Xr) / np.linalg.norm(Xr) < 1e-13 * 10.0 ** log_cond
+
+
+def test_block_copy_and_reshard_down(hbm_store):
+    """HipBackend.block (strided device copy) and matrix_init.reshard_down on device tiles."""
+    from numpywren_amd import matrix_init
+    from numpywren_amd.matrix import BigMatrix
+    from numpywren_amd.matrix_init import shard_matrix
+    be = kernels.get_backend()
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal((70, 45))
+    t = be.to_device(a)
+    assert np.array_equal(be.to_host(be.block(t, 3, 61, 7, 44)), a[3:61, 7:44])
+    assert np.array_equal(be.to_host(be.block(t, 0, 70, 0, 45)), a)
+    f = a.astype(np.float32)
+    assert np.array_equal(be.to_host(be.block(be.to_device(f), 10, 11, 0, 45)), f[10:11])
+    Xh = rng.standard_normal((300, 200))
+    X = BigMatrix("rs_gpu", shape=Xh.shape, shard_sizes=(128, 64), write_header=True)
+    shard_matrix(X, Xh)
+    Y = matrix_init.reshard_down(X, [4, 2])
+    assert tuple(Y.shard_sizes) == (32, 32) and np.array_equal(Y.numpy(), Xh)

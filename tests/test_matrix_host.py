@@ -179,3 +179,24 @@ def test_matrix_utils_row_col_helpers(host_store):
     key = X.__shard_idx_to_key__((2, 1))
     assert matrix_utils.block_key_to_block(key) == ((16, 20), (6, 12))
     assert matrix_utils.block_key_to_block(X.key_base + "/header") is None
+
+
+@pytest.mark.parametrize("store", ["host", "oracle"])
+def test_reshard_down_and_empty_result_matrix(store, request):
+    """matrix_init.reshard_down / empty_result_matrix (reference matrix_init.py:33-49, 100-148)."""
+    request.getfixturevalue("host_store" if store == "host" else "oracle_backend")
+    from numpywren_amd import matrix_init, matrix_utils
+    rng = np.random.default_rng(8)
+    Xh = rng.standard_normal((20, 12))
+    X = BigMatrix("rs_in", shape=Xh.shape, shard_sizes=(8, 6), write_header=True)     # ragged last row block
+    shard_matrix(X, Xh)
+    Y = matrix_init.reshard_down(X, [2, 3])
+    assert Y.key == "reshard(rs_in,[2, 3])" and tuple(Y.shard_sizes) == (4, 2) and tuple(Y.shape) == (20, 12)
+    assert len(Y.block_idxs_exist) == 5 * 6
+    assert np.array_equal(Y.numpy(), Xh)
+    assert np.array_equal(Y.get_block(4, 5), Xh[16:20, 10:12])
+    with pytest.raises(AssertionError):
+        matrix_init.reshard_down(X, [3, 1])
+    E = matrix_init.empty_result_matrix(X, np.sum, (1, 2), shape=(20, 20), shard_sizes=(8, 8))
+    assert E.shape == (20, 20) and E.block_idxs_exist == []
+    assert E.key == matrix_utils.hash_string(matrix_utils.hash_function(np.sum) + "rs_in" + matrix_utils.hash_args((1, 2)))
