@@ -141,6 +141,7 @@ class LambdaPackExecutor(object):
 
     # ---- one task ----
     def run_task(self, expr_idx, var_values):
+        t_enq = time.time()
         task = self.compiled.task(expr_idx, var_values)
         compute = self.compiled.kernel(expr_idx)
         mats = self.compiled.matrices
@@ -202,6 +203,9 @@ class LambdaPackExecutor(object):
         self.program.incr_read(read_bytes)
         self.program.incr_write(write_bytes)
         self._consumed(task)
+        self.program.record_profile(expr_idx, var_values, kernel=getattr(compute, "__name__", str(compute)),
+                                    stream=getattr(stream, "name", str(stream)), enqueue_start=t_enq, enqueue_end=time.time(),
+                                    read_bytes=read_bytes, write_bytes=write_bytes, batch=1)
         return last
 
     # ---- several independent tasks of one kind as one batched kernel call ----
@@ -214,6 +218,7 @@ class LambdaPackExecutor(object):
     def run_batch(self, nodes):
         """Run the ready tasks `nodes` (all of the same expr_idx, whose kernel has a `_npw_batch`) with one call.
         Same reads, writes and bookkeeping as run_task for each of them."""
+        t_enq = time.time()
         expr_idx = nodes[0][0]
         compute = self.compiled.kernel(expr_idx)
         mats = self.compiled.matrices
@@ -245,6 +250,11 @@ class LambdaPackExecutor(object):
             self._consumed(task)
         self.program.incr_read(read_bytes)
         self.program.incr_write(write_bytes)
+        t_end = time.time()
+        for (e, v), task in zip(nodes, tasks):
+            self.program.record_profile(e, v, kernel=getattr(compute, "__name__", str(compute)),
+                                        stream=getattr(stream, "name", str(stream)), enqueue_start=t_enq, enqueue_end=t_end,
+                                        read_bytes=None, write_bytes=None, batch=len(nodes))
         return last
 
     async def run(self, expr_idx, var_values, computer=None, profile=True):

@@ -284,6 +284,7 @@ class LambdaPackProgram(object):
         self._finished_terminators = set()
         self._priority = None
         self.exceptions = {}
+        self.profiles = {}          # node -> per-task record (what the reference pickles to S3 after every task)
         self.info_flags = []        # (device int32 flag, node) pairs checked at completion (Cholesky info)
         self._defer_success = False  # the async runner reports SUCCESS only after the GPU has drained
         self._success_pending = False
@@ -508,6 +509,31 @@ class LambdaPackProgram(object):
 
     def incr_progress(self):
         self._incr("progress")
+
+    # ---- per-task profiling records (reference lambdapack.py:531-533, 765-776: one pickled instruction block per
+    # node under s3://<bucket>/lambdapack/<hash>/<expr>_<vars>) ----
+    def record_profile(self, expr_idx, var_values, **info):
+        with self._lock:
+            self.profiles[self._node_str(expr_idx, var_values)] = dict(info, expr_idx=int(expr_idx), var_values=dict(var_values))
+
+    def get_profiling_info(self, expr_idx, var_values):
+        """The record of one executed task: kernel name, stream, host enqueue window (the GPU runs asynchronously: use
+        rocprofv3 for device times), bytes read / written, flops, size of the batch it ran in."""
+        return self.profiles[self._node_str(expr_idx, var_values)]
+
+    def get_all_profiling_info(self):
+        with self._lock:
+            return list(self.profiles.values())
+
+    def dump_profiling_info(self, inst_block, expr_idx, var_values):
+        import pickle
+        return pickle.dumps(self.profiles.get(self._node_str(expr_idx, var_values)))
+
+    async def begin_write(self, loop=None):
+        return None
+
+    async def begin_read(self, loop=None):
+        return None
 
     def incr_flops(self, amount):
         if amount > 0:

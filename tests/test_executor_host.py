@@ -276,3 +276,22 @@ def test_run_without_waiting_settles_in_program_wait(oracle_backend):
     job_runner.lambdapack_run(program, wait=False)
     program.wait()
     assert program.program_status() == lp.PS.EXCEPTION
+
+
+def test_profiling_records(oracle_backend):
+    """get_profiling_info / get_all_profiling_info (reference lambdapack.py:765-776 read a pickle per node from S3)."""
+    Xh = ALG["tsqr_64_8/X"]
+    X = BigMatrix("tsqr_prof", shape=Xh.shape, shard_sizes=(8, Xh.shape[1]))
+    shard_matrix(X, Xh)
+    program, _ = alg_wrappers.tsqr(X)
+    program.config["executor"]["batch_tasks"] = 4
+    res = run(program)
+    infos = program.get_all_profiling_info()
+    assert len(infos) == len(res["executed_messages"]) == 15
+    e, v = res["executed_messages"][0]
+    rec = program.get_profiling_info(e, v)
+    assert rec["kernel"] == "qr_factor" and rec["expr_idx"] == e and rec["var_values"] == v
+    assert rec["enqueue_end"] >= rec["enqueue_start"] and rec["batch"] in (1, 2, 4)
+    assert max(r["batch"] for r in infos) == 4
+    import pickle
+    assert pickle.loads(program.dump_profiling_info(None, e, v)) == rec
