@@ -406,6 +406,17 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
             "log": pickle.dumps({})}
 
 
+async def lambdapack_run_async(loop, program, computer=None, cache=None, shared_state=None, read_queue=None, pipeline_width=1,
+                               msg_vis_timeout=60, timeout=200, msg_vis_timeout_jitter=15):
+    """Coroutine form of the worker loop (reference job_runner.py:418-: one of `pipeline_width` SQS pollers sharing an
+    event loop).  Here one call drives the whole DAG; `shared_state["running_times"]`, when given, receives the busy
+    intervals as the reference's pollers record them."""
+    res = lambdapack_run(program, pipeline_width=pipeline_width, timeout=timeout)
+    if isinstance(shared_state, dict):
+        shared_state.setdefault("running_times", []).extend(res["exec_time"])
+    return res
+
+
 def lambdapack_run_with_failures(failure_key, program, pipeline_width=5, msg_vis_timeout=60, cache_size=5,
                                  timeout=200, idle_timeout=5, msg_vis_timeout_jitter=15):
     """Signature-compatible with the reference's fault-injection driver (job_runner.py:190-221); a

@@ -295,3 +295,22 @@ def test_profiling_records(oracle_backend):
     assert max(r["batch"] for r in infos) == 4
     import pickle
     assert pickle.loads(program.dump_profiling_info(None, e, v)) == rec
+
+
+def test_lambdapack_run_async_entry(oracle_backend):
+    import asyncio
+    A = ALG["cholesky_32_8/A"]
+    X = BigMatrix("chol_async_in", shape=A.shape, shard_sizes=(8, 8))
+    shard_matrix(X, A)
+    program, meta = alg_wrappers.cholesky(X)
+    program.start()
+    shared = {}
+    loop = asyncio.new_event_loop()
+    try:
+        res = loop.run_until_complete(job_runner.lambdapack_run_async(loop, program, None, None, shared, None))
+    finally:
+        loop.close()
+    program.wait()
+    assert program.program_status() == lp.PS.SUCCESS and "running_times" in shared
+    assert set(res) >= {"up_time", "exec_time", "executed_messages", "operator_refs", "log"}
+    np.testing.assert_allclose(meta["outputs"][0].numpy(), ALG["cholesky_32_8/L"], atol=1e-12)
