@@ -366,6 +366,72 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
     // ---- epilogue: D = alpha * acc + beta * C ------------------------------------------------
     const T alpha = p.alpha, beta = p.beta;
     T* const Dp = p.D + (int64_t)blockIdx.y * p.split_stride;
+
+    // ---- symmetric product (TAG 2, X == Y): a strictly-lower tile also writes its mirror tile --------------------
+    // acc(r, c) = sum_k X[m0 + r, k] X[n0 + c, k] is bit for bit what the workgroup of tile (tile_n, tile_m) would have
+    // summed for element (c, r) (same products, same order), so  D[n0 + c, m0 + r] = beta * C[n0 + c, m0 + r] +
+    // alpha * acc(r, c)  is exactly the full product's upper tile for ANY C -- symmetric or not.  The accumulators
+    // go through LDS (free after the k loop's last barrier) 16 rows at a time so that both the read of C and the
+    // store of D are 128-byte row segments.  Row block i is finished (both tiles) before i + 1 starts, so the
+    // accumulator registers retire as the epilogue proceeds.
+    if constexpr (TAG == 2) {
+        constexpr int LDT = 17;                      // odd stride: ds_write_b64 of a 16 x 16 block is conflict-free
+        T* stage = smem + wave * (64 * LDT);         // 64 x 16 transposed block per wave
+        const bool mirror = (tile_m != tile_n);
+        const bool has_c = (beta != T(0));
+        const int64_t urow0 = n0 + wn0, ucol0 = m0 + wm0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            T cv[TN][4];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cv[j][r] = T(0);
+            if (has_c) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        cv[j][r] = p.C[(int64_t)(m0 + wm0 + 16 * i + TR::acc_row(lg, r)) * p.ldc + n0 + wn0 + 16 * j + li];
+            }
+            if (mirror) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) stage[(16 * j + li) * LDT + TR::acc_row(lg, r)] = acc[i][j][r];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Dp[(int64_t)(m0 + wm0 + 16 * i + TR::acc_row(lg, r)) * p.ldd + n0 + wn0 + 16 * j + li] =
+                        fma(beta, cv[j][r], alpha * acc[i][j][r]);
+            if (mirror) {
+                __syncthreads();
+                const T* crow = p.C + (urow0 + lg) * p.ldc + ucol0 + 16 * i + li;
+                T* drow = Dp + (urow0 + lg) * p.ldd + ucol0 + 16 * i + li;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {        // two batches of 8 rows: the loads of a batch are in flight together
+                    T av[8], uv[8];
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        av[it] = stage[(4 * (8 * h + it) + lg) * LDT + li];
+                        uv[it] = T(0);
+                    }
+                    if (has_c) {
+#pragma unroll
+                        for (int it = 0; it < 8; ++it) uv[it] = crow[(int64_t)(4 * (8 * h + it)) * p.ldc];
+                    }
+#pragma unroll
+                    for (int it = 0; it < 8; ++it)
+                        drow[(int64_t)(4 * (8 * h + it)) * p.ldd] = fma(beta, uv[it], alpha * av[it]);
+                }
+                __syncthreads();
+            }
+        }
+        return;
+    }
+
     // (the beta test is hoisted out of the unrolled loops: a per-element "load or not" select
     //  makes hipcc branch around and wait for every single load)
     if (beta != T(0)) {
@@ -475,28 +541,6 @@ __global__ void splitk_reduce_kernel(int nsplit, const T* P, int64_t stride, int
             if (beta != T(0)) v = fma(beta, C[r * ldc + c], v);
             D[r * ldd + c] = v;
         }
-}
-
-// upper triangle <- transpose of the strictly-lower triangle, 32 x 32 blocks through LDS (both sides coalesced)
-__global__ void mirror_lower_kernel(int64_t n, double* D, int64_t ldd) {
-    __shared__ double tile[32][33];
-    const int64_t nb = (n + 31) / 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    for (int64_t t = blockIdx.x; t < nb * (nb + 1) / 2; t += gridDim.x) {
-        int64_t br = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-        while ((br + 1) * (br + 2) / 2 <= t) ++br;
-        while (br * (br + 1) / 2 > t) --br;
-        const int64_t bc = t - br * (br + 1) / 2;  // bc <= br: a block on or below the diagonal
-        const int64_t r0 = br * 32, c0 = bc * 32;
-        __syncthreads();
-        for (int i = ty; i < 32; i += 8)
-            if (r0 + i < n && c0 + tx < n) tile[i][tx] = D[(r0 + i) * ldd + c0 + tx];
-        __syncthreads();
-        for (int i = ty; i < 32; i += 8) {
-            const int64_t r = c0 + i, c = r0 + tx;  // destination element (r, c) = source (c, r)
-            if (r < n && c < n && c > r) D[r * ldd + c] = tile[tx][i];
-        }
-    }
 }
 
 }  // namespace
@@ -635,11 +679,12 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
         const char* e = getenv("NPW_GEMM_BIG_MIN_SHORTK");
         return e ? (int64_t)atoi(e) : (int64_t)512;  // k <= 256: prologue/epilogue-bound, more workgroups win
     }();
-    const bool big = (wg128 >= (k <= 256 ? big_min_shortk : big_min));
+    const bool big = opts.force_big || (wg128 >= (k <= 256 ? big_min_shortk : big_min));
     if (big) {
         p.tiles_m = (int)ceil_div(m, 128);
         p.tiles_n = (int)ceil_div(n, 128);
         const bool full = vec_ok && k_ok && (m % 128 == 0) && (n % 128 == 0);
+        NPW_REQUIRE(full || opts.tag != 2, "gemm: the symmetric (tag 2) product needs full, aligned 128 x 128 tiles");
         if (full) return dispatch_layout<T, 128, 128, BK, false>(a_kc, b_kc, p, stream);
         return dispatch_layout<T, 128, 128, BK, true>(a_kc, b_kc, p, stream);
     }
@@ -682,11 +727,16 @@ int npw_sgemm(char transA, char transB, int64_t m, int64_t n, int64_t k, float a
 
 namespace {
 constexpr int kDiagSplit = 8;  // k chunks of the diagonal-block launch of the symmetric trailing update
-bool nt_sub_symmetric_split(int64_t m, int64_t n) { return m == n && m % 128 == 0 && m >= 2048; }
+// X == Y takes the symmetric route when the tagged full-tile kernel applies: square, whole 128 x 128 tiles, k a multiple
+// of the k-tile, 16-byte aligned rows; big enough that halving the tile count matters.
+bool nt_sub_symmetric(int64_t m, int64_t n, int64_t k, const double* X, int64_t ldx, const double* Y, int64_t ldy) {
+    return X == Y && ldx == ldy && m == n && m % 128 == 0 && m >= 1024 && k > 0 && k % 16 == 0 && ldx % 2 == 0 &&
+           (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+}
 }  // namespace
 
 size_t npw_dgemm_nt_sub_workspace_bytes(int64_t m, int64_t n, int64_t k) {
-    if (!nt_sub_symmetric_split(m, n) || k < 1024) return 0;
+    if (m != n || m % 128 != 0 || m < 1024 || k < 1024) return 0;
     return (size_t)(m / 128) * kDiagSplit * 128 * 128 * sizeof(double);
 }
 
@@ -698,51 +748,37 @@ int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t l
     o.skip0 = skip_x;
     o.skip1 = skip_y;
     o.tag = 1;
-    // X == Y (the diagonal tiles of the trailing matrix): X X^T is symmetric bit for bit (element (i, j) and
-    // (j, i) sum the same products in the same order), so only the tiles touching the lower triangle are
-    // computed and the strict upper triangle is filled by transposition.  S is a diagonal tile of a
-    // symmetric matrix here; if its two triangles differ, the lower one wins (as in LAPACK's 'L' routines).
-    const bool sym = (X == Y && ldx == ldy && m == n && m >= 256 && k > 0);
-    if (!sym)
+    // X == Y (the diagonal tiles of the trailing matrix): X X^T is symmetric bit for bit (element (i, j) and (j, i)
+    // sum the same products in the same order), so only the strictly-lower 128 x 128 tiles are multiplied; each of
+    // their workgroups writes BOTH D tiles of its pair from its accumulators (S is read at both positions, so the
+    // result is the full S - X X^T for any S, symmetric or not; reference kernels.py:212-215).
+    if (!nt_sub_symmetric(m, n, k, X, ldx, Y, ldy))
         return npw::gemm<double>('N', 'T', m, n, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, o,
                                  npw::as_stream(stream));
     o.tag = 2;
     o.lower_only = true;
-    int rc;
-    if (nt_sub_symmetric_split(m, n)) {
-        // 2 workgroups share a CU, so the chip holds 512 tiles at a time: the 496 strictly-lower tiles of a
-        // 4096^2 output are one full wave of work, the 32 diagonal tiles would be a second, nearly empty one.
-        // They go into their own small batched launch (lower 64 x 64 sub-tiles only) instead.
-        o.strict_lower = true;
-        rc = npw::gemm<double>('N', 'T', m, n, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, o, npw::as_stream(stream));
-        if (rc) return rc;
-        npw::GemmOpts d;
-        d.skip0 = skip_x;
-        d.skip1 = skip_y;
-        d.lower_only = true;
-        d.batch = (int)(m / 128);
-        d.batch_a = d.batch_b = 128 * ldx;
-        d.batch_c = 128 * (lds + 1);
-        d.batch_d = 128 * (ldd + 1);
-        if (workspace != nullptr && npw_dgemm_nt_sub_workspace_bytes(m, n, k) > 0) {
-            // 96 workgroups with the full k would run alone for 0.18 ms: cut k into chunks (8x the workgroups,
-            // partial products summed in a fixed order)
-            NPW_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "npw_dgemm_nt_sub: workspace not 16B aligned");
-            d.lower_only = false;
-            d.splitk = kDiagSplit;
-            d.splitk_ws = workspace;
-        }
-        rc = npw::gemm<double>('N', 'T', 128, 128, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, d, npw::as_stream(stream));
-    } else {
-        rc = npw::gemm<double>('N', 'T', m, n, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, o, npw::as_stream(stream));
-    }
+    o.strict_lower = true;
+    o.force_big = true;
+    // 2 workgroups share a CU, so the chip holds 512 tiles at a time: the 496 strictly-lower tiles of a 4096^2
+    // output are one full wave of work, the 32 diagonal tiles would be a second, nearly empty one.  They go into
+    // their own small batched launch instead (full 128 x 128 blocks).
+    int rc = npw::gemm<double>('N', 'T', m, n, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, o, npw::as_stream(stream));
     if (rc) return rc;
-    const int64_t nb = (n + 31) / 32;
-    const int64_t tiles = nb * (nb + 1) / 2;
-    hipLaunchKernelGGL(npw::mirror_lower_kernel, dim3((unsigned)(tiles < 8192 ? tiles : 8192)), dim3(256), 0,
-                       npw::as_stream(stream), n, D, ldd);
-    NPW_LAUNCH_CHECK();
-    return NPW_OK;
+    npw::GemmOpts d;
+    d.skip0 = skip_x;
+    d.skip1 = skip_y;
+    d.batch = (int)(m / 128);
+    d.batch_a = d.batch_b = 128 * ldx;
+    d.batch_c = 128 * (lds + 1);
+    d.batch_d = 128 * (ldd + 1);
+    if (workspace != nullptr && npw_dgemm_nt_sub_workspace_bytes(m, n, k) > 0) {
+        // 128 workgroups with the full k would run alone for 0.18 ms: cut k into chunks (8x the workgroups,
+        // partial products summed in a fixed order)
+        NPW_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "npw_dgemm_nt_sub: workspace not 16B aligned");
+        d.splitk = kDiagSplit;
+        d.splitk_ws = workspace;
+    }
+    return npw::gemm<double>('N', 'T', 128, 128, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, d, npw::as_stream(stream));
 }
 
 }  // extern "C"

@@ -49,7 +49,9 @@ struct GemmOpts {
     const int32_t* skip1 = nullptr;
     bool lower_only = false;  // only output tiles touching the lower triangle are computed/written
     bool inplace_a = false;   // D aliases A (row panel update, n <= 128): forces one tile column
-    int tag = 0;              // 1 = tile-level trailing update (separate kernel symbol for profiling)
+    int tag = 0;              // 1 = tile-level trailing update (separate kernel symbol for profiling); 2 = its symmetric
+                              // form (op(A) op(B) = X X^T, strict_lower): every tile also writes its mirror tile
+    bool force_big = false;   // take the 128 x 128 tiling whatever the grid size
     int splitk = 1;           // > 1 with splitk_ws: cut k into this many chunks (skinny outputs, long k)
     void* splitk_ws = nullptr;  // splitk * m * n elements of scratch
     int* splitk_keep = nullptr;  // non-NULL: leave the partial products in splitk_ws ([problem][split][m][n], alpha and

@@ -664,11 +664,10 @@ class HipBackend(object):
         flag.streams.add(sh)
         r, c = t64.rows_cols()
         _ffi.check(self.lib.npw_is_zero(t64.ptr, r, c, c, atol, flag.ptr, sh), "is_zero")
-        # the flag is only ever consumed on streams that also wait for the tile; give the tile an
-        # event that covers the flag kernel when it ran on a different stream than the producer
-        if tile.ready is None or tile.ready[1] != sh:
-            ev = self.record_new(sh)
-            tile.ready = (ev, sh)
+        # The flag is only ever consumed on streams that also wait for the tile (`_use`), so the tile's event must cover
+        # the flag kernels: ALWAYS a fresh event recorded behind them -- also when they ran on the producer's own stream,
+        # whose earlier event says nothing about the flag (a consumer on another stream would read it half-computed).
+        tile.ready = _Ready(self.record_new(sh), sh, self)
         tile.zero_flag = flag
         return flag
 
@@ -743,8 +742,9 @@ class HipBackend(object):
             fy = fx if Y is X else self.zero_flag(Y, sh)
         out = S if (inplace and not S.shared) else self.empty((m, n), _F64)
         self._use(sh, S, X, Y, out)
-        # X is Y on the diagonal tiles: the library then computes the lower tiles only and mirrors them
-        tname = "syrk_sym" if (X.ptr == Y.ptr and m == n and m >= 256) else "syrk"
+        # X is Y on the diagonal tiles: the library multiplies the strictly-lower 128 x 128 tiles only, each workgroup
+        # writing both tiles of its pair (the full s - x x^T for any s)
+        tname = "syrk_sym" if (X.ptr == Y.ptr and m == n and m % 128 == 0 and m >= 1024 and k % 16 == 0) else "syrk"
         ws = None
         if X.ptr == Y.ptr:
             nbytes = self.lib.npw_dgemm_nt_sub_workspace_bytes(m, n, k)

@@ -154,7 +154,9 @@ class LambdaPackExecutor(object):
         exclusive = len(self.streams) > 1 and getattr(compute, "_npw_needs_whole_cus", False)
         others = [s for s in self.streams if s is not stream] if exclusive else []
         for o in others:
-            self.be.wait_event(stream, self.be.record_new(o))
+            ev = self.be.record_new(o)
+            self.be.wait_event(stream, ev)
+            self.be.recycle_event(ev)   # (a stream wait captures the event's state when it is enqueued)
         tiles = [mats[m].get_tile(*idx, stream=stream) for m, idx in task.reads]
         read_bytes = sum(t.nbytes for t in tiles)
         if device_kernel:
@@ -170,6 +172,7 @@ class LambdaPackExecutor(object):
             ev = self.be.record_new(stream)
             for o in others:
                 self.be.wait_event(o, ev)
+            self.be.recycle_event(ev)
         flops_fn = getattr(compute, "flops", None)
         if flops_fn is not None:
             try:
@@ -379,6 +382,8 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
                 if marks is None or wait:
                     be.synchronize()
                     ok = check_info_flags(program, be)
+                    for ev in (marks or []):
+                        be.recycle_event(ev)
                 else:
                     for ev in marks:
                         be.event_sync(ev)   # (events stay alive: a later run may still be told to wait for them)

@@ -458,6 +458,15 @@ class LambdaPackProgram(object):
             finish()
         status = self.program_status()
         while status == PS.RUNNING:
+            if self.get_up() == 0:
+                # Nobody is driving this program any more (a run left its loop on a timeout or on a stalled DAG) and, unlike
+                # the reference's fleet, no other worker can pick it up: report instead of sleeping forever.
+                with self._lock:
+                    pending = len(self._ready)
+                self.handle_exception(RuntimeError(
+                    "program is still RUNNING but no worker is up ({0} ready tasks left): lambdapack_run timed out or the "
+                    "DAG stalled; call lambdapack_run again to resume".format(pending)), tb="", expr_idx=-1, var_values={})
+                break
             time.sleep(sleep_time)
             status = self.program_status()
 

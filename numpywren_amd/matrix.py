@@ -237,11 +237,31 @@ class BigMatrix(object):
         fn = self.parent_fn
         res = fn(self, None, *block_idx)
         if inspect.isawaitable(res):
-            loop = asyncio.new_event_loop()
+            def drive(coro):
+                loop = asyncio.new_event_loop()
+                try:
+                    return loop.run_until_complete(coro)
+                finally:
+                    loop.close()
             try:
-                res = loop.run_until_complete(res)
-            finally:
-                loop.close()
+                asyncio.get_running_loop()
+            except RuntimeError:
+                return drive(res)
+            # called from inside a running event loop (get_block_async, RemoteRead.__call__, LambdaPackExecutor.run):
+            # a second loop cannot run on this thread, so the parent coroutine gets a thread of its own
+            box = {}
+
+            def worker():
+                try:
+                    box["v"] = drive(res)
+                except BaseException as e:   # re-raised on the caller's thread
+                    box["e"] = e
+            t = threading.Thread(target=worker, name="npw-parent-fn")
+            t.start()
+            t.join()
+            if "e" in box:
+                raise box["e"]
+            return box["v"]
         return res
 
     def _raw(self, block_idx):
