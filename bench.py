@@ -7,9 +7,10 @@
 metric : achieved fp64 TFLOP/s of an N x N tiled Cholesky (4096^2 tiles) = (N^3 / 3) / wall, whole job.
 step   : one complete factorisation (alg_wrappers.cholesky -> LambdaPACK DAG -> HIP-stream executor)
          of a synthetic SPD matrix whose tiles are already resident in HBM when the clock starts.
-N = 1  : BASELINE.json configs[1], 16384 x 16384.  N > 1: tiles 2-D block-cyclic over the ranks,
-         panel tiles exchanged over RCCL (numpywren_amd/dist.py); the problem grows with the GPU count
-         (4 / 8 / 12 / 16 tiles per side for 1 / 2 / 4 / 8 GPUs; 8 GPUs = configs[2], 65536 x 65536).
+N = 1  : BASELINE.json configs[1], 16384 x 16384 (+ a `north_star` object: configs[2]'s 65536 x 65536 matrix on
+         this ONE GPU, 3 steps).  N > 1: STRONG scaling of the 65536 x 65536 matrix (configs[2] at N = 8): tiles 2-D
+         block-cyclic over the ranks, panel tiles pushed point-to-point over RCCL / xGMI by libnpw_hip.so's
+         npw_comm_* layer (numpywren_amd/dist.py).  --workload tsqr / gemm32 time configs[3] / configs[4] the same way.
 Input  : tile (i, j) = X_i X_j^T + N * I[i == j], X = N x 128 counter-based standard normals generated on
          the device (SURVEY.md section 8d generator (ii)).  The reference experiment's own generator
          (x x^T + 20e12 N I) is NOT used for timing: with that diagonal shift every panel tile is < 1e-8,
@@ -17,7 +18,7 @@ Input  : tile (i, j) = X_i X_j^T + N * I[i == j], X = N x 128 counter-based stan
 Extra objects on the JSON line (N = 1 only): `roofline` for the dominant kernel -- the syrk trailing
 update, 2 * 4096^3 flop per launch, timed with HIP events on its launching stream inside the timed
 steps -- and `cpu_baseline`: the oracle's tile Cholesky (NumPy / SciPy, the reference's kernel path
-restated) on the host cores of this box.
+restated) on the host cores of this box, at the best BLAS thread count of a sweep and at 1 thread.
 """
 import argparse
 import json
@@ -32,8 +33,8 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense fp64 matrix peak (vendor spec; 74.6 measured by tools/devcheck)
 TILE = 4096
-SYRK_TRAFFIC_BYTES = 2.27e9    # measured, see profiles/r01_bench_rocprof_summary.md
-TILES_PER_SIDE = {1: 4, 2: 8, 4: 12, 8: 16}
+SYRK_TRAFFIC_BYTES = 2.27e9    # PMC passes of a separate run (2 x FETCH_SIZE + WRITE_SIZE per launch of the tagged kernel)
+SYRK_TRAFFIC_SOURCE = "profiles/r01_bench_rocprof_summary.md"
 
 
 def build_input(be, nb, b, key, rank=0, world=1, owner=None):
@@ -61,19 +62,17 @@ def build_input(be, nb, b, key, rank=0, world=1, owner=None):
     return X
 
 
-def cpu_baseline(b, budget_s=25.0):
-    """Oracle (kind = "port") timed on this box's host cores on a bounded sample of the same workload."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import npw_oracle as oracle
-    rng = np.random.default_rng(0)
-    probe = 2048
-    a = rng.standard_normal((probe, probe))
-    t0 = time.time()
-    oracle.syrk(a, a, a)
-    gflops = 2 * probe ** 3 / max(time.time() - t0, 1e-6) / 1e9
-    executed = {nb: (nb * b ** 3 / 3 + nb * (nb - 1) / 2 * b ** 3 + sum((nb - i - 1) * (nb - i) / 2 for i in range(nb)) * 2 * b ** 3)
-                for nb in (4, 3, 2, 1)}
-    nb = next((k for k in (4, 3, 2, 1) if executed[k] / (gflops * 1e9 * 0.7) < budget_s), 1)
+def _blas_threads(n):
+    """Context manager limiting the BLAS thread pool (threadpoolctl when present, else a no-op)."""
+    try:
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=int(n))
+    except Exception:
+        import contextlib
+        return contextlib.nullcontext()
+
+
+def _oracle_tile_cholesky(oracle, b, nb, rng):
     n = nb * b
     X = rng.standard_normal((n, 128))
     tiles = {}
@@ -85,11 +84,61 @@ def cpu_baseline(b, budget_s=25.0):
             tiles[(i, j)] = t
     t0 = time.time()
     oracle.cholesky_tiles_inplace(tiles, nb)
-    dt = time.time() - t0
-    return {"value": round((n ** 3 / 3) / dt / 1e12, 4), "unit": "TFLOP/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"oracle tile Cholesky (NumPy/SciPy BLAS+LAPACK, all host threads) of a {n} x {n} fp64 matrix, "
-                      f"{b}^2 tiles, {dt:.2f} s; probe syrk {gflops:.0f} GFLOP/s",
-            "blas": _blas_name()}
+    return n, time.time() - t0
+
+
+def cpu_baseline(b, budget_s=12.0):
+    """Oracle (kind = "port": the reference's NumPy / SciPy kernel path restated, oracle/npw_oracle.py) timed on this
+    box's host cores on a bounded sample of the same workload.  A fair one: the BLAS thread count is swept on a
+    2048^3 syrk probe and the tile Cholesky runs at the best setting AND at 1 thread -- the reference's per-worker
+    default (experiments/cholesky_experiment.py:66,367) -- each sample sized to ~`budget_s` seconds; config 1's
+    4096^2 single-tile gemm is timed at both settings as well."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import npw_oracle as oracle
+    rng = np.random.default_rng(0)
+    ncpu = os.cpu_count() or 1
+    probe = 2048
+    a = rng.standard_normal((probe, probe))
+    sweep = {}
+    for th in sorted({1, 32, 64, 128, ncpu} & set(range(1, ncpu + 1)) | {1, ncpu}):
+        with _blas_threads(th):
+            oracle.syrk(a, a, a)                       # warm the pool at this size
+            t0 = time.time()
+            oracle.syrk(a, a, a)
+            sweep[th] = round(2 * probe ** 3 / max(time.time() - t0, 1e-6) / 1e9, 1)
+    best = max(sweep, key=sweep.get)
+
+    def executed(nb):   # flops the tile DAG executes (chol b^3/3, trsm b^3, syrk 2 b^3)
+        return (nb * b ** 3 / 3 + nb * (nb - 1) / 2 * b ** 3 + sum((nb - i - 1) * (nb - i) / 2 for i in range(nb)) * 2 * b ** 3)
+
+    out = {"unit": "TFLOP/s", "kind": "port", "blas": _blas_name(), "probe_syrk_2048_gflops_by_threads": sweep}
+    for label, th in (("best", best), ("one_thread", 1)):
+        nb = next((k for k in (4, 3, 2, 1) if executed(k) / (sweep[th] * 1e9 * 0.7) < budget_s), 1)
+        with _blas_threads(th):
+            n, dt = _oracle_tile_cholesky(oracle, b, nb, rng)
+        out[label] = {"threads": th, "tflops": round((n ** 3 / 3) / dt / 1e12, 4), "n": n, "seconds": round(dt, 2)}
+    # config 1: one 4096^2 fp64 kernels.gemm on the CPU path (median of 5 at the best setting, of 3 at one thread)
+    A, B_ = rng.standard_normal((b, b)), rng.standard_normal((b, b))
+    gem = {}
+    for label, th, reps in (("best", best, 5), ("one_thread", 1, 3)):
+        with _blas_threads(th):
+            if label == "best":
+                oracle.gemm(A, B_)
+            ts = []
+            for _ in range(reps):
+                t0 = time.time()
+                oracle.gemm(A, B_)
+                ts.append(time.time() - t0)
+        gem[label] = {"threads": th, "median_s": round(float(np.median(ts)), 4),
+                      "tflops": round(2 * b ** 3 / float(np.median(ts)) / 1e12, 4)}
+    out["config1_gemm_4096"] = gem
+    out["value"] = out["best"]["tflops"]
+    out["cores"] = out["best"]["threads"]
+    out["sample"] = (f"oracle tile Cholesky (NumPy/SciPy BLAS+LAPACK) of a {out['best']['n']}^2 fp64 matrix, {b}^2 tiles, at the "
+                     f"best BLAS thread count of the sweep ({best}; {out['best']['seconds']} s) and of a "
+                     f"{out['one_thread']['n']}^2 one at 1 thread, the reference worker's default "
+                     f"({out['one_thread']['seconds']} s)")
+    return out
 
 
 def _blas_name():
@@ -100,18 +149,113 @@ def _blas_name():
         return "unknown"
 
 
+def _prebuild(build, count):
+    """Compile `count` programs before the clock starts (the reference reports compile_time separately,
+    alg_wrappers.py:20-24); scheduling, every kernel and every exchange stay inside the timed region."""
+    out = []
+    for _ in range(count):
+        program, meta = build()
+        program.program.tasks
+        program._priorities()
+        out.append((program, meta))
+    return out
+
+
+class Runner(object):
+    """Times K runs of one alg_wrappers program after W warm-up runs, bracketed by a barrier + device synchronise."""
+
+    def __init__(self, be, comm, streams, priority_stream=False):
+        self.be, self.comm, self.streams, self.priority_stream = be, comm, streams, priority_stream
+        self.pending = []   # (program, meta) enqueued on the device, not yet waited for
+
+    def settle(self):
+        from numpywren_amd import lambdapack as lp
+        while self.pending:
+            program, _ = self.pending.pop(0)
+            program.wait()
+            if program.program_status() != lp.PS.SUCCESS:
+                raise SystemExit(f"program failed: {program.exceptions}")
+            program.free()
+
+    def one_step(self, program, meta):
+        """One run.  On one GPU the step is enqueued and the PREVIOUS one is waited for afterwards (program.wait() is
+        where the reference's call sequence waits, too), so the host-side turnaround between two runs does not leave
+        the GPU idle.  Steps do not overlap on the device (each waits for the previous one's completion events);
+        every step is complete before the closing barrier."""
+        from numpywren_amd import job_runner
+        from numpywren_amd import lambdapack as lp
+        for m in meta["outputs"] + meta["intermediates"]:
+            m.free()
+        program.config["executor"]["reclaim_intermediates"] = True
+        program.config["executor"]["priority_stream"] = self.priority_stream
+        program.start()
+        if self.comm is None:
+            marks = self.pending[-1][0].completion_marks if self.pending else None
+            job_runner.lambdapack_run(program, pipeline_width=self.streams, timeout=3600, wait=False, after=marks)
+            self.settle()
+            self.pending.append((program, meta))
+        else:
+            from numpywren_amd import dist
+            dist.lambdapack_run_distributed(program, self.comm, pipeline_width=self.streams, timeout=3600)
+            if program.program_status() != lp.PS.SUCCESS:
+                raise SystemExit(f"program failed: {program.exceptions}")
+        return meta
+
+    def barrier(self):
+        self.settle()
+        if self.comm is not None:
+            self.comm.barrier()
+        self.be.synchronize()
+
+    def timed(self, build, steps, warmup, timers=None):
+        progs = _prebuild(build, steps + warmup)
+        for _ in range(warmup):
+            self.one_step(*progs.pop(0))
+        if timers and self.comm is None:
+            self.barrier()
+            self.be.enable_kernel_timers(timers)
+        self.barrier()
+        t0 = time.time()
+        for _ in range(steps):
+            meta = self.one_step(*progs.pop(0))
+        self.barrier()
+        elapsed = time.time() - t0
+        if self.comm is not None:
+            elapsed = self.comm.max_over_ranks(elapsed)
+        return elapsed, meta
+
+
+def cholesky_residual(be, X, O, nb, full=False):
+    """|| A - L L^T ||_F / || A ||_F on the device: all tiles (full=True) or the tile (1, 1)."""
+    num = den = 0.0
+    todo = [(i, j) for i in range(nb) for j in range(i + 1)] if full else [(1, 1) if nb > 1 else (0, 0)]
+    for i, j in todo:
+        a = X.get_tile(i, j)
+        r = a
+        for k in range(j + 1):
+            r = be.gemm(O.get_tile(i, k), O.get_tile(j, k), False, True, alpha=-1.0, beta=1.0, C=r)
+        w = 1.0 if i == j else 2.0
+        num += w * be.sumsq(r)
+        den += w * be.sumsq(a)
+    return float(np.sqrt(num / den))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--tiles", type=int, default=0, help="tiles per side (default: by GPU count)")
+    ap.add_argument("--workload", choices=["chol", "tsqr", "gemm32"], default="chol",
+                    help="chol = the headline (BASELINE.json configs[1] / [2]); tsqr = configs[3]; gemm32 = configs[4]")
+    ap.add_argument("--tiles", type=int, default=0, help="tiles per side (default: 4 on one GPU, 16 on several)")
+    ap.add_argument("--leaves", type=int, default=0, help="tsqr: number of 4096-row leaves (default 64 per GPU, at most 256)")
     ap.add_argument("--tile", type=int, default=TILE)
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams per rank (0 = 1 on one GPU, 3 with several: a task waiting for a tile in "
                          "transit must not block the tasks behind it)")
     ap.add_argument("--priority-stream", action="store_true", help="panel kernels on a high-priority stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-north-star", action="store_true", help="skip the 65536^2 single-GPU run of the N = 1 line")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,123 +266,124 @@ def main():
     if args.streams <= 0:
         args.streams = 1 if world == 1 else 3
 
-    from numpywren_amd import alg_wrappers, job_runner
-    from numpywren_amd import lambdapack as lp
+    from numpywren_amd import alg_wrappers
     from numpywren_amd.device import get_backend
+    from numpywren_amd.matrix import BigMatrix
 
     comm = None
     if world > 1 or os.environ.get("NUMPYWREN_AMD_FORCE_DIST"):   # the env var exercises the N > 1 code path on 1 GPU
         from numpywren_amd import dist
-        comm = dist.init_process_group()   # RCCL over xGMI, one process per GPU
+        comm = dist.init_process_group()   # control: gloo; payload: RCCL over xGMI (npw_comm_*), one process per GPU
     be = get_backend()
     b = args.tile
-    nb = args.tiles or TILES_PER_SIDE.get(args.gpus, 4 * args.gpus)
-    n = nb * b
+    run = Runner(be, comm, args.streams, args.priority_stream)
+    par = "1 gpu" if world == 1 else f"{world} gpus, one process each, tiles 2-D block-cyclic, RCCL p2p panel exchange (npw_comm_*)"
 
-    owner = None
-    if comm is not None:
-        owner = comm.owner_fn(nb)
-    X = build_input(be, nb, b, f"bench_chol_{n}_{b}", rank, world, owner)
-
-    # programs are compiled before the clock starts (the reference reports compile_time separately,
-    # alg_wrappers.py:20-24); scheduling, every kernel and every exchange are inside the timed region
-    prebuilt = []
-    for _ in range(args.warmup + args.steps):
-        program, meta = alg_wrappers.cholesky(X)
-        program.program.tasks
-        program._priorities()
-        prebuilt.append((program, meta))
-
-    pending = []   # (program, meta) enqueued on the device, not yet waited for
-
-    def settle():
-        while pending:
-            program, _ = pending.pop(0)
-            program.wait()
-            if program.program_status() != lp.PS.SUCCESS:
-                raise SystemExit(f"cholesky failed: {program.exceptions}")
-            program.free()
-
-    def one_step():
-        """One factorisation.  On one GPU the step is enqueued and the PREVIOUS one is waited for afterwards
-        (program.wait() is where the reference's call sequence waits, too), so the host-side turnaround between two
-        factorisations does not leave the GPU idle.  Steps do not overlap on the device (each waits for the previous
-        one's completion events); every step is complete before the closing barrier."""
-        program, meta = prebuilt.pop(0)
-        for m in meta["outputs"] + meta["intermediates"]:
-            m.free()
-        program.config["executor"]["reclaim_intermediates"] = True
-        program.config["executor"]["priority_stream"] = args.priority_stream
-        program.start()
-        if comm is None:
-            # device-side order: this factorisation starts after the previous one has finished on the GPU (no overlap
-            # of two steps); only the host runs ahead
-            marks = pending[-1][0].completion_marks if pending else None
-            job_runner.lambdapack_run(program, pipeline_width=args.streams, timeout=3600, wait=False, after=marks)
-            settle()
-            pending.append((program, meta))
-        else:
-            from numpywren_amd import dist
-            dist.lambdapack_run_distributed(program, comm, pipeline_width=args.streams, timeout=3600)
-            if program.program_status() != lp.PS.SUCCESS:
-                raise SystemExit(f"cholesky failed: {program.exceptions}")
-        return meta
-
-    def barrier():
-        settle()
+    if args.workload == "chol":
+        # N = 1: configs[1] (16384^2).  N > 1: STRONG scaling of configs[2]'s 65536^2 matrix (it fits one GPU: 34 GB).
+        nb = args.tiles or (4 if world == 1 else 16)
+        n = nb * b
+        owner = comm.owner_fn(nb) if comm is not None else None
+        X = build_input(be, nb, b, f"bench_chol_{n}_{b}", rank, world, owner)
+        elapsed, meta = run.timed(lambda: alg_wrappers.cholesky(X), args.steps, args.warmup,
+                                  timers=("syrk", "syrk_sym", "trsm", "chol"))
+        flops = n ** 3 / 3.0
+        value = args.steps * flops / elapsed / 1e12
+        line = {"metric": "achieved fp64 TFLOP/s, N x N tiled Cholesky (N^3/3 / wall)", "value": round(value, 3),
+                "unit": "TFLOP/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+                "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"{n}x{n} fp64 Cholesky, {b}^2 tiles, {nb}x{nb} tile grid, alg_wrappers.cholesky "
+                                       f"via LambdaPACK DAG ({nb*(nb+1)*(nb+2)//6} tasks)",
+                           "n": n, "tile": b, "streams": args.streams, "parallelism": par,
+                           "pct_fp64_mfma_peak": round(100 * value / (FP64_MFMA_PEAK_TFLOPS * args.gpus), 2)}}
+        if world == 1:
+            times = be.collect_kernel_times()
+            syrk = times.get("syrk", [])
+            if syrk:
+                avg_ms = float(np.mean(syrk))
+                achieved = 2.0 * b ** 3 / (avg_ms * 1e-3) / 1e12
+                line["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<double,128,128,16,true,true,false,1> (kernels.syrk: S - X Y^T, 1024 workgroups)",
+                                    "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
+                                    # HBM-side bytes per launch: PMC passes of ANOTHER run of this command (2 x FETCH_SIZE +
+                                    # WRITE_SIZE, profiles/), not measured in this process; only for the 4096^2 tile
+                                    "traffic": SYRK_TRAFFIC_BYTES if b == TILE else None,
+                                    "traffic_unit": "B/launch; from " + SYRK_TRAFFIC_SOURCE + ", not this run (algorithmic 5.37e8)",
+                                    "launches": len(syrk), "avg_ms": round(avg_ms, 4),
+                                    "algorithmic_flop_per_launch": 2 * b ** 3}
+                line["kernel_ms"] = {k: round(float(np.mean(v)), 4) for k, v in times.items() if v}
+            # parity guard at full size: || A - L L^T ||_F / || A ||_F over ALL tiles (device side)
+            line["config"]["residual_all_tiles"] = cholesky_residual(be, X, meta["outputs"][0], nb, full=True)
+            if not args.no_north_star and b == TILE and nb == 4:
+                # the north-star configuration on one GPU: configs[2]'s 65536^2 matrix (816 tasks), a few steps
+                X.free()
+                for m in meta["outputs"] + meta["intermediates"]:
+                    m.free()
+                nb2 = 16
+                n2 = nb2 * b
+                X2 = build_input(be, nb2, b, f"bench_chol_{n2}_{b}")
+                ns_steps = 3
+                e2, meta2 = run.timed(lambda: alg_wrappers.cholesky(X2), ns_steps, 1, timers=("syrk",))
+                t2 = be.collect_kernel_times().get("syrk", [])
+                tf = ns_steps * (n2 ** 3 / 3.0) / e2 / 1e12
+                line["north_star"] = {"n": n2, "tile": b, "tasks": nb2 * (nb2 + 1) * (nb2 + 2) // 6, "steps": ns_steps,
+                                      "ms_per_step": round(e2 / ns_steps * 1e3, 2), "tflops": round(tf, 3),
+                                      "pct_peak": round(100 * tf / FP64_MFMA_PEAK_TFLOPS, 2),
+                                      "syrk_frac": round(2.0 * b ** 3 / (float(np.mean(t2)) * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if t2 else None,
+                                      "syrk_launches": len(t2),
+                                      "residual_tile_1_1": cholesky_residual(be, X2, meta2["outputs"][0], nb2)}
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(b)
+    elif args.workload == "tsqr":
+        # configs[3]: (leaves * 4096) x 4096 fp64 TSQR; leaves in contiguous chunks per GPU, log2(world) exchanged R factors
+        leaves = args.leaves or min(256, 64 * world)
+        m = leaves * b
         if comm is not None:
-            comm.barrier()
+            from numpywren_amd import dist
+            comm.ownership = dist.tsqr_ownership(world, leaves)
+        X = BigMatrix(f"bench_tsqr_{m}", shape=(m, b), shard_sizes=(b, b))
+        for j in range(leaves):
+            if comm is None or comm.owner("A", (j, 0)) == rank:
+                X.put_tile(be.fill_random((b, b), 7, j * b, 0), j, 0)
         be.synchronize()
-
-    for _ in range(args.warmup):
-        one_step()
-    if world == 1:
-        be.enable_kernel_timers(("syrk", "syrk_sym", "trsm", "chol"))
-    barrier()
-    t0 = time.time()
-    for _ in range(args.steps):
-        meta = one_step()
-    barrier()
-    elapsed = time.time() - t0
+        elapsed, meta = run.timed(lambda: alg_wrappers.tsqr(X), args.steps, args.warmup)
+        flops = 2.0 * m * b * b - 2.0 * b ** 3 / 3
+        value = args.steps * flops / elapsed / 1e12
+        line = {"metric": "achieved fp64 TFLOP/s, m x n TSQR ((2 m n^2 - 2 n^3 / 3) / wall)", "value": round(value, 3),
+                "unit": "TFLOP/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+                "scaling": "strong" if args.leaves else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"{m}x{b} fp64 TSQR, {leaves} leaves, alg_wrappers.tsqr ({2 * leaves - 1} tasks)",
+                           "tile": b, "streams": args.streams, "parallelism": par}}
+    else:
+        # configs[4]: 32768^2 fp32 GEMM program (fp32 MFMA products, the reference's fp64 add_matrices tree), strong scaling
+        nb = args.tiles or 8
+        n = nb * b
+        if comm is not None:
+            from numpywren_amd import dist
+            comm.ownership = dist.gemm_ownership(world)
+        A = BigMatrix(f"bench_gA_{n}", shape=(n, n), shard_sizes=(b, b), dtype=np.float32)
+        B = BigMatrix(f"bench_gB_{n}", shape=(n, n), shard_sizes=(b, b), dtype=np.float32)
+        for i in range(nb):
+            for j in range(nb):
+                if comm is None or comm.owner("A", (i, j)) == rank:
+                    A.put_tile(be.convert(be.fill_random((b, b), 11, i * b, j * b), np.float32), i, j)
+                if comm is None or comm.owner("B", (i, j)) == rank:
+                    B.put_tile(be.convert(be.fill_random((b, b), 12, i * b, j * b), np.float32), i, j)
+        be.synchronize()
+        elapsed, meta = run.timed(lambda: alg_wrappers.gemm(A, B), args.steps, args.warmup)
+        value = args.steps * 2.0 * n ** 3 / elapsed / 1e12
+        line = {"metric": "achieved fp32 TFLOP/s, N x N GEMM program (2 N^3 / wall)", "value": round(value, 3),
+                "unit": "TFLOP/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"{n}x{n} fp32 GEMM, {b}^2 tiles, alg_wrappers.gemm (fp32 MFMA products, fp64 "
+                                       f"add_matrices tree as in the reference)", "tile": b, "streams": args.streams,
+                           "parallelism": par, "pct_fp32_mfma_peak": round(100 * value / (157.3 * args.gpus), 2)}}
     if comm is not None:
-        elapsed = comm.max_over_ranks(elapsed)
-
-    flops = n ** 3 / 3.0
-    value = args.steps * flops / elapsed / 1e12
-    line = {"metric": "achieved fp64 TFLOP/s, N x N tiled Cholesky (N^3/3 / wall)", "value": round(value, 3),
-            "unit": "TFLOP/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{n}x{n} fp64 Cholesky, {b}^2 tiles, {nb}x{nb} tile grid, alg_wrappers.cholesky "
-                                   f"via LambdaPACK DAG ({nb*(nb+1)*(nb+2)//6} tasks)",
-                       "n": n, "tile": b, "streams": args.streams,
-                       "parallelism": "1 gpu" if world == 1 else f"{world} gpus, 2-D block-cyclic tiles, RCCL p2p panel exchange",
-                       "pct_fp64_mfma_peak": round(100 * value / (FP64_MFMA_PEAK_TFLOPS * args.gpus), 2)}}
-    if world == 1:
-        times = be.collect_kernel_times()
-        syrk = times.get("syrk", [])
-        if syrk:
-            avg_ms = float(np.mean(syrk))
-            achieved = 2.0 * b ** 3 / (avg_ms * 1e-3) / 1e12
-            line["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<double,128,128,16,true,true,false,1> (kernels.syrk: S - X Y^T, 1024 workgroups)",
-                                "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
-                                # HBM-side bytes per launch from the PMC passes of profiles/r01_bench_rocprof_summary.md
-                                # (2 x FETCH_SIZE + WRITE_SIZE); only meaningful for the 4096^2 tile it was measured on
-                                "traffic": SYRK_TRAFFIC_BYTES if b == TILE else None,
-                                "traffic_unit": "B/launch (PMC, separate passes; algorithmic 5.37e8)",
-                                "launches": len(syrk), "avg_ms": round(avg_ms, 4),
-                                "algorithmic_flop_per_launch": 2 * b ** 3}
-            line["kernel_ms"] = {k: round(float(np.mean(v)), 4) for k, v in times.items() if v}
-        # parity guard at full size: || A - L L^T ||_F / || A ||_F on the diagonal-block row 0..1 (cheap, device side)
-        O = meta["outputs"][0]
-        L00, L10, L11 = O.get_tile(0, 0), O.get_tile(1, 0), O.get_tile(1, 1)
-        A11 = X.get_tile(1, 1)
-        r = be.gemm(L10, L10, False, True, alpha=-1.0, beta=1.0, C=A11)
-        r = be.gemm(L11, L11, False, True, alpha=-1.0, beta=1.0, C=r)
-        line["config"]["residual_tile_1_1"] = float(np.sqrt(be.sumsq(r) / be.sumsq(A11)))
-        if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(b)
+        line["config"]["transport"] = comm.backend
+        line["config"]["bytes_sent_rank0"] = comm.bytes_sent
     if rank == 0:
         print(json.dumps(line))
     if comm is not None:

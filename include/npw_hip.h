@@ -279,6 +279,48 @@ int npw_fill_random(double* A, int64_t rows, int64_t cols, int64_t lda, uint64_t
 int npw_dsumsq(const double* A, int64_t rows, int64_t cols, int64_t lda, double* out_dev,
                npw_stream_t stream);
 
+/* ---- tile transport between the GPUs of one node: RCCL over xGMI --------------------
+ * Replaces the reference's only way to move a tile from one worker to another: an S3 PUT
+ * by the producer and an S3 GET by every consumer (reference numpywren/matrix.py:508
+ * `get_object`, :527 `put_object`; RemoteRead / RemoteWrite, lambdapack.py:96-186).  One
+ * process per GPU; a tile stays in the HBM of its producer and is pushed to the GPUs that
+ * own a consumer task.  librccl is loaded on the first npw_comm_* call (dlopen), never by
+ * a single-GPU process.
+ *
+ *   npw_comm_unique_id  rank 0 creates the rendezvous id (ncclGetUniqueId) and hands its
+ *                       NPW_COMM_ID_BYTES bytes to the other ranks over any side channel
+ *                       (dist.py: the gloo control group; a file or a socket do as well).
+ *   npw_comm_init       ncclCommInitRank on the calling thread's current device + the
+ *                       rank's transport stream (high priority).  Collective over ranks.
+ *   npw_send_tile /     one tile = `bytes` raw bytes of device memory.  Asynchronous on
+ *   npw_recv_tile       `stream` (NULL = the communicator's transport stream): order them
+ *                       behind the producer / ahead of the consumers with events.  Every
+ *                       pair of ranks must issue its transfers in the same order.
+ *   npw_bcast_tile      the panel broadcast: root -> members as k grouped sends on k xGMI
+ *                       links (one fused launch); on a member, the matching receive into
+ *                       `tile`; on other ranks a no-op.
+ *   npw_sendrecv_tile   grouped exchange with two peers (the TSQR butterfly of R factors).
+ *   npw_allgather_tiles every rank contributes bytes_per_rank and receives world * that.
+ *   npw_allreduce_max_f64  small control values (timings, failure flags), device memory.
+ *   npw_comm_group_start / _end   bracket several transfers into one launch.             */
+#define NPW_COMM_ID_BYTES 128
+typedef void* npw_comm_t;
+int npw_comm_unique_id(void* id_out, size_t id_bytes);
+int npw_comm_init(npw_comm_t* comm, int rank, int world, const void* unique_id);
+int npw_comm_destroy(npw_comm_t comm);
+int npw_comm_info(npw_comm_t comm, int* rank, int* world, npw_stream_t* transport_stream);
+int npw_comm_group_start(npw_comm_t comm);
+int npw_comm_group_end(npw_comm_t comm);
+int npw_send_tile(npw_comm_t comm, const void* tile, size_t bytes, int dst, npw_stream_t stream);
+int npw_recv_tile(npw_comm_t comm, void* tile, size_t bytes, int src, npw_stream_t stream);
+int npw_bcast_tile(npw_comm_t comm, void* tile, size_t bytes, int root, const int* members, int nmembers,
+                   npw_stream_t stream);
+int npw_sendrecv_tile(npw_comm_t comm, const void* send, size_t send_bytes, int dst, void* recv,
+                      size_t recv_bytes, int src, npw_stream_t stream);
+int npw_allgather_tiles(npw_comm_t comm, const void* send, void* recv, size_t bytes_per_rank,
+                        npw_stream_t stream);
+int npw_allreduce_max_f64(npw_comm_t comm, double* values, size_t count, npw_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,7 +92,20 @@ PROTOTYPES = {
     "npw_fill_outer": (c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, c_double, _vp]),
     "npw_fill_random": (c_int, [_vp, _i64, _i64, _i64, c_uint64, _i64, _i64, _vp]),
     "npw_dsumsq": (c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "npw_comm_unique_id": (c_int, [_vp, _sz]),
+    "npw_comm_init": (c_int, [POINTER(_vp), c_int, c_int, _vp]),
+    "npw_comm_destroy": (c_int, [_vp]),
+    "npw_comm_info": (c_int, [_vp, POINTER(c_int), POINTER(c_int), POINTER(_vp)]),
+    "npw_comm_group_start": (c_int, [_vp]),
+    "npw_comm_group_end": (c_int, [_vp]),
+    "npw_send_tile": (c_int, [_vp, _vp, _sz, c_int, _vp]),
+    "npw_recv_tile": (c_int, [_vp, _vp, _sz, c_int, _vp]),
+    "npw_bcast_tile": (c_int, [_vp, _vp, _sz, c_int, POINTER(c_int), c_int, _vp]),
+    "npw_sendrecv_tile": (c_int, [_vp, _vp, _sz, c_int, _vp, _sz, c_int, _vp]),
+    "npw_allgather_tiles": (c_int, [_vp, _vp, _vp, _sz, _vp]),
+    "npw_allreduce_max_f64": (c_int, [_vp, _vp, _sz, _vp]),
 }
+NPW_COMM_ID_BYTES = 128
 
 
 def library_path():

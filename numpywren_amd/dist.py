@@ -18,15 +18,20 @@ counterpart keeps the tiles where they are produced and moves only what another 
                  identical on both sides (the NCCL/RCCL requirement) and no collective is needed on the
                  data path.  xGMI is point-to-point: a panel tile needed by k GPUs is k independent
                  128 MiB sends on k links rather than a ring broadcast.
-  * overlap:     payload sends are posted as soon as the tile is produced (HIP event -> torch stream
-                 -> RCCL), payload receives are asynchronous (consumers wait on the tile's event on
-                 the device).  A 48-byte header (shape, dtype) travels on the CPU side channel (gloo)
-                 because `safe=False` matrices hold tiles whose shape only the producer knows.
+  * transport:   libnpw_hip.so's npw_comm_* entry points (include/npw_hip.h: grouped ncclSend / ncclRecv on a
+                 dedicated high-priority HIP stream per rank).  A send is posted when the producing task is
+                 enqueued and waits on the device for the producer's event only; a receive lands in a tile of
+                 the backend's own allocator whose event the consumers wait for.  No torch tensors on the data
+                 path, no staging copies, no host synchronisation.
+  * metadata:    receivers derive shape and dtype of a tile from the static plan (TileMetaPlan: one rule per
+                 Cholesky / GEMM kernel); only tiles of kernels without a rule (the QR family, whose `safe=False`
+                 matrices hold tiles of data-dependent shapes) send a 48-byte header over the control group.
+  * control:     torch.distributed over gloo -- rendezvous (the RCCL unique id), barriers, max-over-ranks.
 
-The same code runs on CPU under gloo with host tiles (tests/test_dist_gloo.py) and on GPUs under the
-"nccl" backend, which is RCCL on ROCm.
+The same code runs on CPU with the host transport (tests/test_dist_gloo.py).
 """
 import collections
+import ctypes
 import os
 import pickle
 import time
@@ -34,9 +39,10 @@ import traceback
 
 import numpy as np
 
+from . import _ffi
 from . import job_runner
 from . import lambdapack as lp
-from .device import DeviceBuffer, DeviceTile, get_backend
+from .device import DeviceTile, Stream, get_backend
 
 _DTYPES = [np.dtype(np.float64), np.dtype(np.float32), np.dtype(np.int32), np.dtype(np.int64)]
 
@@ -49,21 +55,122 @@ def process_grid(world):
     return pr, world // pr
 
 
+class TileMeta(tuple):
+    """(shape, dtype, upper) of a tile: what a receiver must know before it can post the matching receive."""
+
+    def __new__(cls, shape, dtype, upper=False):
+        return tuple.__new__(cls, (tuple(int(x) for x in shape), np.dtype(dtype), bool(upper)))
+
+    shape = property(lambda self: self[0])
+    dtype = property(lambda self: self[1])
+    upper = property(lambda self: self[2])
+
+    @property
+    def nbytes(self):
+        return int(np.prod(self[0], dtype=np.int64)) * self[1].itemsize
+
+
+class RcclTransport(object):
+    """Payload path for one-GPU-per-rank runs: libnpw_hip.so's npw_comm_* entry points (RCCL point-to-point over xGMI).
+    A tile is sent straight out of the buffer its producer wrote and received straight into a buffer of the backend's
+    allocator (so the store's HBM budget and out-of-memory hook see it); both run on the communicator's transport
+    stream, ordered behind the producer by the tile's event and ahead of the consumers by the received tile's event.
+    No torch tensors, no staging copies, no host synchronisation."""
+    name = "rccl"
+
+    def __init__(self, rank, world, control):
+        self.be = get_backend()          # binds this process to its device (LOCAL_RANK) before the communicator exists
+        self.lib = self.be.lib
+        ident = [None]
+        if rank == 0:
+            buf = ctypes.create_string_buffer(_ffi.NPW_COMM_ID_BYTES)
+            _ffi.check(self.lib.npw_comm_unique_id(buf, _ffi.NPW_COMM_ID_BYTES), "npw_comm_unique_id")
+            ident[0] = buf.raw
+        if world > 1:
+            control.broadcast_object_list(ident, src=0)   # the rendezvous id travels over the control group
+        h = ctypes.c_void_p(0)
+        idbuf = ctypes.create_string_buffer(ident[0], _ffi.NPW_COMM_ID_BYTES)
+        _ffi.check(self.lib.npw_comm_init(ctypes.byref(h), rank, world, idbuf), "npw_comm_init")
+        self.handle = h.value
+        sh = ctypes.c_void_p(0)
+        _ffi.check(self.lib.npw_comm_info(self.handle, None, None, ctypes.byref(sh)), "npw_comm_info")
+        self.stream = Stream(sh.value, True, "xgmi")
+        self.rank, self.world = rank, world
+
+    def send(self, tile, dsts):
+        be, cs = self.be, self.stream
+        be._use(cs, tile)                 # after the producer; the buffer is not recycled before the send has left
+        if len(dsts) == 1:
+            _ffi.check(self.lib.npw_send_tile(self.handle, tile.ptr, tile.nbytes, int(dsts[0]), cs.handle), "npw_send_tile")
+        else:
+            arr = (ctypes.c_int * len(dsts))(*[int(d) for d in dsts])
+            _ffi.check(self.lib.npw_bcast_tile(self.handle, tile.ptr, tile.nbytes, self.rank, arr, len(dsts), cs.handle),
+                       "npw_bcast_tile")
+
+    def recv(self, src, meta):
+        be, cs = self.be, self.stream
+        tile = be.empty(meta.shape, meta.dtype)
+        be._use(cs, tile)
+        _ffi.check(self.lib.npw_recv_tile(self.handle, tile.ptr, tile.nbytes, int(src), cs.handle), "npw_recv_tile")
+        be._produced(cs, tile)
+        tile.upper = meta.upper
+        return tile
+
+    def flush(self):
+        self.be.stream_sync(self.stream)
+
+    def close(self):
+        if self.handle:
+            self.lib.npw_comm_destroy(self.handle)
+            self.handle = None
+
+
+class HostTransport(object):
+    """Payload path over the gloo control group, staged through host memory: the CPU tests (checker backend) and
+    several ranks sharing ONE GPU (RCCL refuses two ranks on a device) -- never a production path."""
+    name = "host"
+
+    def __init__(self, rank, world, control):
+        import torch
+        self.torch, self.control = torch, control
+        self.rank, self.world = rank, world
+
+    def send(self, tile, dsts):
+        arr = np.ascontiguousarray(get_backend().to_host(tile))
+        flat = self.torch.from_numpy(arr.reshape(-1).view(np.uint8).copy())
+        for d in dsts:
+            self.control.send(flat, int(d))
+
+    def recv(self, src, meta):
+        flat = self.torch.empty(max(meta.nbytes, 1), dtype=self.torch.uint8)
+        self.control.recv(flat, int(src))
+        arr = flat.numpy()[:meta.nbytes].view(meta.dtype).reshape(meta.shape)
+        tile = get_backend().to_device(arr)
+        tile.upper = meta.upper
+        return tile
+
+    def flush(self):
+        pass
+
+    def close(self):
+        pass
+
+
 class Comm(object):
-    """Tile exchange over torch.distributed (payload: RCCL for device tensors, gloo on CPU)."""
+    """One rank's view of the job: ownership map, the control group (torch.distributed over gloo: barriers, a handful
+    of scalars, tile headers for dynamically shaped tiles) and the payload transport."""
     ownership = None  # optional algorithm-aware map (matrix_name, idx) -> rank or None (see tsqr_ownership)
 
-    def __init__(self, rank, world, backend, device_tensors):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        self.rank, self.world, self.backend = rank, world, backend
-        self.device_tensors = device_tensors
+    def __init__(self, rank, world, transport, control):
+        self.dist = control
+        self.rank, self.world = rank, world
+        self.transport = transport
+        self.backend = transport.name if transport is not None else "none"
         self.grid = process_grid(world)
         self.bytes_sent = 0
         self.bytes_received = 0
         self.transfers = 0
-        self._pending = []  # (work handle, keep-alive objects)
+        self.headers = 0     # tiles whose (shape, dtype) had to travel over the control group
 
     # ---- ownership ----
     def owner(self, matrix_name, idx):
@@ -81,120 +188,177 @@ class Comm(object):
     def owner_fn(self, nb=None):
         return self.owner
 
-    # ---- control-plane collectives ----
+    # ---- control-plane collectives (host side, tiny) ----
     def barrier(self):
-        self.dist.barrier()
+        if self.world > 1:
+            self.dist.barrier()
 
     def max_over_ranks(self, value):
-        t = self.torch.tensor([float(value)], dtype=self.torch.float64)
-        if self.device_tensors and "gloo" not in self.backend:
-            t = t.cuda()
+        if self.world == 1:
+            return float(value)
+        import torch
+        t = torch.tensor([float(value)], dtype=torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
     def shutdown(self):
         self.flush()
+        self.transport.close()
         try:
-            self.dist.destroy_process_group()
+            if self.dist.is_initialized():
+                self.dist.destroy_process_group()
         except Exception:
             pass
 
     def flush(self):
-        for work, _ in self._pending:
-            work.wait()
-        self._pending = []
-
-    def _trim(self):
-        if len(self._pending) > 32:
-            self._pending = [(w, a) for w, a in self._pending if not w.is_completed()]
+        self.transport.flush()
 
     # ---- tile transport ----
     def _send_header(self, tile, dst):
+        import torch
         hdr = np.zeros(6, dtype=np.int64)
         hdr[0] = len(tile.shape)
         hdr[1:1 + len(tile.shape)] = tile.shape
         # dtype code + what the producer knows about the tile's structure (an R factor stays one on arrival)
         hdr[5] = _DTYPES.index(np.dtype(tile.dtype)) + (16 if getattr(tile, "upper", False) else 0)
-        self.dist.send(self.torch.from_numpy(hdr), dst)
+        self.dist.send(torch.from_numpy(hdr), dst)
 
     def _recv_header(self, src):
-        hdr = self.torch.zeros(6, dtype=self.torch.int64)
+        import torch
+        hdr = torch.zeros(6, dtype=torch.int64)
         self.dist.recv(hdr, src)
         h = hdr.numpy()
-        return tuple(int(x) for x in h[1:1 + int(h[0])]), _DTYPES[int(h[5]) & 15], bool(int(h[5]) & 16)
+        return TileMeta(tuple(int(x) for x in h[1:1 + int(h[0])]), _DTYPES[int(h[5]) & 15], bool(int(h[5]) & 16))
 
-    def send_tile(self, tile, dst):
+    def send_tile(self, tile, dsts, known=False):
+        """Push `tile` to the ranks `dsts` (one grouped launch on the transport stream).  known=True: the receivers
+        derived the tile's shape and dtype from the static plan (TileMetaPlan), nothing but the payload travels;
+        otherwise a 48-byte header goes ahead of it over the control group."""
+        if isinstance(dsts, int):
+            dsts = [dsts]
         if len(tile.shape) > 4:
             raise ValueError("tiles with more than 4 dimensions cannot be exchanged")
-        torch = self.torch
-        be = get_backend()
-        self._send_header(tile, dst)
-        if self.device_tensors:
-            # stage into a torch-owned tensor on torch's current stream, ordered after the producer
-            ts = torch.cuda.current_stream().cuda_stream
-            staging = torch.empty(max(tile.nbytes, 1), dtype=torch.uint8, device="cuda")
-            if tile.ready is not None and tile.ready[1] != ts:
-                be.wait_event(ts, tile.ready[0])
-            tile.buf.streams.add(ts)
-            be.lib.npw_memcpy_d2d_async(staging.data_ptr(), tile.ptr, tile.nbytes, ts)
-            work = self.dist.isend(staging, dst)
-            self._pending.append((work, (staging, tile)))
-        else:
-            arr = np.ascontiguousarray(be.to_host(tile))
-            self.dist.send(torch.from_numpy(arr.reshape(-1).view(np.uint8).copy()), dst)
-        self.bytes_sent += tile.nbytes
-        self.transfers += 1
-        self._trim()
+        if not known:
+            for d in dsts:
+                self._send_header(tile, d)
+            self.headers += len(dsts)
+        self.transport.send(tile, dsts)
+        self.bytes_sent += tile.nbytes * len(dsts)
+        self.transfers += len(dsts)
 
-    def recv_tile(self, src):
-        torch = self.torch
-        be = get_backend()
-        shape, dtype, upper = self._recv_header(src)
-        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
-        self.bytes_received += nbytes
-        if self.device_tensors:
-            buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device="cuda")
-            work = self.dist.irecv(buf, src)
-            work.wait()  # stream-level: torch's current stream now waits for the transfer
-            ts = torch.cuda.current_stream().cuda_stream
-            dbuf = DeviceBuffer(None, buf.data_ptr(), nbytes)
-            dbuf.aux = {"keepalive": buf}
-            dbuf.streams.add(ts)
-            tile = DeviceTile(dbuf, shape, dtype)
-            tile.ready = (be.record_new(ts), ts)
-            tile.upper = upper
-            return tile
-        flat = torch.empty(max(nbytes, 1), dtype=torch.uint8)
-        self.dist.recv(flat, src)
-        arr = flat.numpy()[:nbytes].view(dtype).reshape(shape)
-        tile = be.to_device(arr)
-        tile.upper = upper
+    def recv_tile(self, src, meta=None):
+        if meta is None:
+            meta = self._recv_header(src)
+            self.headers += 1
+        tile = self.transport.recv(src, meta)
+        self.bytes_received += meta.nbytes
         return tile
 
 
 def init_process_group(backend=None):
-    """torch.distributed process group from the torchrun environment (RANK / WORLD_SIZE / MASTER_*).
-    backend: None -> "cpu:gloo,cuda:nccl" when a GPU is visible (nccl is RCCL on ROCm), else "gloo"."""
-    import torch
+    """Join the job described by the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
+
+    The control group is torch.distributed over gloo (host side: rendezvous, barriers, a few scalars).  The PAYLOAD
+    transport is libnpw_hip.so's RCCL layer (`npw_comm_*`, one communicator per rank on its own GPU) unless
+    backend / $NUMPYWREN_AMD_DIST_BACKEND says "gloo" or the ranks have to share a device -- then tiles are staged
+    through the host over the control group (CPU tests; several ranks on the one GPU of a test box)."""
+    import datetime
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    gpu = torch.cuda.is_available()
-    if backend is None:
-        # NUMPYWREN_AMD_DIST_BACKEND=gloo stages payloads through the host: lets several ranks share one GPU
-        # (RCCL refuses two ranks on one device), which is how the GPU-side logic is tested on a 1-GPU box
-        backend = os.environ.get("NUMPYWREN_AMD_DIST_BACKEND") or ("cpu:gloo,cuda:nccl" if gpu else "gloo")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")
-    if "nccl" in backend:
-        local = int(os.environ.get("LOCAL_RANK", str(rank)))
-        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
     if not dist.is_initialized():
-        import datetime
-        # a lost peer must end the run with an error, not hang it: collectives / p2p time out
+        # a lost peer must end the run with an error, not hang it: control-plane operations time out
         limit = datetime.timedelta(seconds=int(os.environ.get("NUMPYWREN_AMD_DIST_TIMEOUT", "900")))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=limit)
-    return Comm(rank, world, backend, device_tensors=("nccl" in backend))
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=limit)
+    want = backend or os.environ.get("NUMPYWREN_AMD_DIST_BACKEND") or "auto"
+    use_rccl = False
+    if "gloo" not in want:
+        from .device import hip_available
+        if hip_available():
+            n = ctypes.c_int(0)
+            _ffi.lib().npw_device_count(ctypes.byref(n))
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+            use_rccl = n.value >= local_world          # one device per rank, or the ranks cannot all hold a communicator
+            if not use_rccl and want in ("rccl", "nccl"):
+                raise RuntimeError(f"RCCL transport needs one GPU per rank ({local_world} ranks, {n.value} devices)")
+    transport = (RcclTransport if use_rccl else HostTransport)(rank, world, dist)
+    return Comm(rank, world, transport, dist)
+
+
+# ------------------------------------------------------------------------------------------------
+# static tile metadata: what every rank can derive about every tile of the plan without asking anybody
+# ------------------------------------------------------------------------------------------------
+def _f32_iff_all(*metas):
+    return np.dtype(np.float32) if all(m.dtype == np.float32 for m in metas) else np.dtype(np.float64)
+
+
+def _meta_gemm(a, b, transpose_A=False, transpose_B=False, **kw):
+    m = a.shape[1] if transpose_A else a.shape[0]
+    n = b.shape[0] if transpose_B else b.shape[1]
+    return [TileMeta((m, n), a.dtype if a.dtype == b.dtype else np.float64)]
+
+
+_META_RULES = {
+    "gemm": _meta_gemm,
+    "syrk": lambda s, x, y, **kw: [TileMeta(s.shape, _f32_iff_all(s, x, y))],
+    "trsm": lambda x, y, **kw: [TileMeta(y.shape, np.float64)],
+    "chol": lambda x, **kw: [TileMeta(x.shape, x.dtype)],
+    "add_matrices": lambda *a, **kw: [TileMeta(a[0].shape, np.float64)],
+    "identity": lambda x, **kw: [x],
+}
+
+
+class TileMetaPlan(object):
+    """Shape / dtype of every tile the program touches, propagated through the static task sequence with one rule per
+    kernel (the arithmetic of the Cholesky and GEMM programs).  Every rank computes the same table, so a receiver can
+    allocate and post its receive without a header from the producer.  Tiles of kernels without a rule (the QR
+    family, user callables) or of inputs whose stored shape is not the nominal block shape stay unknown -> header."""
+
+    def __init__(self, compiled):
+        self.compiled = compiled
+        self.table = {}
+
+    def _input_meta(self, name, idx):
+        m = self.compiled.matrices[name]
+        try:
+            blocks = [m._blocks(ax)[i] for ax, i in enumerate(idx)]
+        except Exception:
+            return None
+        shape = tuple(int(e - s) for s, e in blocks)
+        if getattr(m, "autosqueeze", True):
+            shape = tuple(x for x in shape if x != 1) or (1,)
+        return TileMeta(shape, m.dtype)
+
+    def read(self, name, idx):
+        key = (name, tuple(idx))
+        if key in self.table:
+            return self.table[key]
+        if self.compiled.writer_of(name, idx) is not None:
+            return None          # produced by a task we have no rule for
+        m = self.compiled.matrices[name]
+        if name not in self.compiled.inputs and getattr(m, "parent_fn", None) is not None:
+            zs = getattr(m.parent_fn, "_npw_zero_shape", None)   # never written: a parent_fn zero tile
+            return TileMeta(zs(m, tuple(idx)), np.float64) if zs is not None else None
+        return self._input_meta(name, idx)
+
+    def visit(self, task, kernel_name):
+        """Record the metas of `task`'s outputs (call in plan order)."""
+        rule = _META_RULES.get(kernel_name)
+        outs = None
+        if rule is not None:
+            ins = [self.read(*r) for r in task.reads]
+            if all(i is not None for i in ins):
+                try:
+                    args = [ins[j] for kind, j in task.arg_kinds if kind == "tile"]
+                    outs = rule(*args, **task.kwargs)
+                except Exception:
+                    outs = None
+        if outs is not None and len(outs) == len(task.writes):
+            for w, o in zip(task.writes, outs):
+                self.table[(w[0], tuple(w[1]))] = o
+        return outs
 
 
 def _consumer_ranks(comm, task):
@@ -233,8 +397,40 @@ def tsqr_ownership(world, num_leaves, input_name="A"):
     return own
 
 
+def gemm_ownership(world):
+    """Ownership for the GEMM program (reference algs.py:251-266): every partial product Temp[i, j, k, l] and the
+    output Out[i, j] live with the C tile (i, j) on the Pr x Pc grid, so the reduction tree of a C tile is local and
+    only input tiles move: A[i, k] to the Pc GPUs of grid row i, B[k, j] to the Pr GPUs of grid column j (SUMMA's
+    traffic, pushed point-to-point in the prologue and consumed as the tiles arrive).  The generic map would own
+    Temp by its (k, l) indices.  Install with `comm.ownership = gemm_ownership(world)`."""
+    pr, pc = process_grid(world)
+
+    def own(name, idx):
+        if name == "Temp" and len(idx) == 4:
+            return (idx[0] % pr) * pc + (idx[1] % pc)
+        return None
+    return own
+
+
+def _stored_tile(bigm, idx):
+    """The tile as stored (no `lambdav` shift: the receiver's own reads apply it), or the parent_fn / host form."""
+    obj = bigm._raw(tuple(idx))[0] if hasattr(bigm, "_raw") else None
+    if isinstance(obj, DeviceTile):
+        return obj
+    return bigm.get_tile(*idx)
+
+
 def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, max_inflight=64):
-    """Distributed counterpart of job_runner.lambdapack_run: every rank calls it with the same program."""
+    """Distributed counterpart of job_runner.lambdapack_run: every rank calls it with the same program.
+
+    Transfers are posted on the transport stream at the point of the common task sequence where the tile is produced:
+    the producer's sends wait (on the device) for the producing kernel only -- not for the trailing updates queued
+    behind it on the compute streams -- so a panel tile leaves as soon as its trsm has finished and the consumers'
+    receives were posted long before; the panel exchange overlaps the trailing updates of the previous step."""
+    if getattr(program, "block_sparse", False):
+        # an owner that skips storing a zero tile would never post the send its consumers wait for
+        raise NotImplementedError("lambdapack_run_distributed: block_sparse programs are not supported (every planned "
+                                  "transfer must have a payload); run them on one GPU")
     program.incr_up(1)
     t_start = time.time()
     be = get_backend()
@@ -247,12 +443,13 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
         send_plan=lambda t: _consumer_ranks(comm, t))
     mats = compiled.matrices
     inputs = set(compiled.inputs)
+    metas = TileMetaPlan(compiled)
     executed = []
     inflight = collections.deque()
     program._defer_success = True
     try:
-        # prologue: input tiles read by tasks that live on another rank than the tile itself
-        moved = set()
+        # prologue: input tiles read by tasks that live on another rank than the tile itself (one grouped push per tile)
+        moves = collections.OrderedDict()
         for t in compiled.tasks:
             if not t.writes:
                 continue
@@ -260,12 +457,16 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
             for r in dict.fromkeys(t.reads):
                 if r[0] in inputs and compiled.writer_of(*r) is None:
                     home = comm.owner(*r)
-                    if home != consumer and (r, consumer) not in moved:
-                        moved.add((r, consumer))
-                        if rank == home:
-                            comm.send_tile(mats[r[0]].get_tile(*r[1]), consumer)
-                        elif rank == consumer:
-                            mats[r[0]].put_tile(comm.recv_tile(home), *r[1])
+                    if home != consumer:
+                        moves.setdefault(r, (home, []))
+                        if consumer not in moves[r][1]:
+                            moves[r][1].append(consumer)
+        for r, (home, consumers) in moves.items():
+            meta = metas.read(*r)
+            if rank == home:
+                comm.send_tile(_stored_tile(mats[r[0]], r[1]), consumers, known=meta is not None)
+            elif rank in consumers:
+                mats[r[0]].put_tile(comm.recv_tile(home, meta), *r[1])
         while program.program_status() == lp.PS.RUNNING and not program.all_terminators_done():
             node = program.dequeue()
             if node is None:
@@ -297,16 +498,16 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
                         be.wait_tile(inflight.popleft())
             # push the outputs to the remote consumers: both sides evaluate the same static plan here
             for (ge, gv), task, owner in zip(group, tasks, owners):
+                kname = getattr(compiled.kernel(ge), "__name__", "")
+                out_metas = metas.visit(task, kname)
                 for pos, ranks in _consumer_ranks(comm, task).items():
                     name, idx = task.writes[pos]
+                    meta = out_metas[pos] if out_metas is not None else None
                     if rank == owner:
-                        if mats[name].tile_exists(*idx):
-                            tile = mats[name].get_tile(*idx)
-                            for dst in ranks:
-                                comm.send_tile(tile, dst)
-                            ex.sent(name, idx)
+                        comm.send_tile(_stored_tile(mats[name], idx), ranks, known=meta is not None)
+                        ex.sent(name, idx)
                     elif rank in ranks:
-                        mats[name].put_tile(comm.recv_tile(owner), *idx)
+                        mats[name].put_tile(comm.recv_tile(owner, meta), *idx)
                 program.post_op(ge, gv, lp.PS.SUCCESS, None)
                 program.set_node_status(ge, gv, lp.NS.FINISHED)
         comm.flush()
@@ -325,7 +526,8 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
         program.decr_up(1)
     return {"up_time": [t_start, time.time()], "exec_time": [], "executed_messages": executed,
             "operator_refs": [tuple(x) for x in executed], "log": pickle.dumps({}),
-            "bytes_sent": comm.bytes_sent, "bytes_received": comm.bytes_received, "transfers": comm.transfers}
+            "bytes_sent": comm.bytes_sent, "bytes_received": comm.bytes_received, "transfers": comm.transfers,
+            "headers": comm.headers}
 
 
 def gather_matrix(bigm, comm, root=0):

@@ -43,5 +43,34 @@ def test_bench_runs_and_prints_one_json_line():
     assert len(lines) == 1
     line = json.loads(lines[0])
     _check_line(line)
-    assert line["config"]["residual_tile_1_1"] < 1e-13
+    assert line["config"]["residual_all_tiles"] < 1e-13
     assert line["roofline"]["traffic"] is None            # PMC figure only applies to the 4096^2 tile
+    assert "north_star" not in line                       # only with the full-size tile
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,extra", [("tsqr", ["--leaves", "8"]), ("gemm32", ["--tiles", "2"])])
+def test_bench_other_configs(workload, extra):
+    """--workload tsqr / gemm32 (BASELINE.json configs[3] / [4]) through the same runner, reduced sizes."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--tile", "512",
+           "--workload", workload] + extra
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    for k, t in REQUIRED.items():
+        assert k in line and isinstance(line[k], t), k
+    assert line["value"] > 0 and line["dtype"] == ("f64" if workload == "tsqr" else "f32")
+
+
+@pytest.mark.gpu
+def test_bench_distributed_path_on_one_gpu():
+    """The N > 1 code path of bench.py (dist.init_process_group -> RCCL transport -> lambdapack_run_distributed) with a
+    world of one."""
+    env = dict(os.environ, NUMPYWREN_AMD_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29661")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--tile", "512",
+           "--tiles", "4", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["config"]["transport"] == "rccl" and line["value"] > 0

@@ -1,0 +1,86 @@
+"""The RCCL transport of the C-ABI (npw_comm_*) on the one GPU of the test box.
+
+A single device cannot hold two ranks of one communicator, so what runs here is everything that does not need a
+second GPU: loading librccl on demand, rendezvous id + communicator creation, the transport stream, a grouped
+self send/receive of a real tile through ncclSend / ncclRecv, the degenerate collectives of a world of one, and the
+distributed executor over the RCCL transport (`dist.init_process_group()` -> RcclTransport) for a world of one.  The
+exchange logic for world > 1 is covered with the host transport in tests/test_dist_gloo.py (CPU, world 2 / 4) and
+tests/test_dist_gpu.py (HIP kernels, 2 / 4 ranks sharing this GPU); the driver's 8-GPU run is the first place both
+halves meet."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_comm_world_of_one_self_exchange():
+    from numpywren_amd import _ffi
+    from numpywren_amd.device import Stream, get_backend
+    be = get_backend()
+    lib = be.lib
+    ident = ctypes.create_string_buffer(_ffi.NPW_COMM_ID_BYTES)
+    _ffi.check(lib.npw_comm_unique_id(ident, _ffi.NPW_COMM_ID_BYTES), "unique_id")
+    assert any(ident.raw)
+    h = ctypes.c_void_p(0)
+    _ffi.check(lib.npw_comm_init(ctypes.byref(h), 0, 1, ident), "comm_init")
+    rank, world, sh = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_void_p(0)
+    _ffi.check(lib.npw_comm_info(h, ctypes.byref(rank), ctypes.byref(world), ctypes.byref(sh)))
+    assert (rank.value, world.value) == (0, 1) and sh.value
+    cs = Stream(sh.value, True, "xgmi")
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((512, 384))
+    src = be.to_device(a)
+    dst = be.zeros(a.shape)
+    be._use(cs, src, dst)
+    # a tile sent to ourselves: the send and the matching receive in one group (one launch), on the transport stream,
+    # ordered behind the H2D copy by the tile's event
+    _ffi.check(lib.npw_comm_group_start(h))
+    _ffi.check(lib.npw_send_tile(h, src.ptr, src.nbytes, 0, cs.handle), "send")
+    _ffi.check(lib.npw_recv_tile(h, dst.ptr, dst.nbytes, 0, cs.handle), "recv")
+    _ffi.check(lib.npw_comm_group_end(h))
+    be._produced(cs, dst)
+    assert np.array_equal(be.to_host(dst), a)
+    # the same through the exchange helper
+    dst2 = be.zeros(a.shape)
+    be._use(cs, dst2)
+    _ffi.check(lib.npw_sendrecv_tile(h, src.ptr, src.nbytes, 0, dst2.ptr, dst2.nbytes, 0, cs.handle), "sendrecv")
+    be._produced(cs, dst2)
+    assert np.array_equal(be.to_host(dst2), a)
+    # world of one: all-gather is a copy, max-reduction the identity, a broadcast without other members a no-op
+    out = be.zeros(a.shape)
+    be._use(cs, out)
+    _ffi.check(lib.npw_allgather_tiles(h, src.ptr, out.ptr, src.nbytes, cs.handle), "allgather")
+    be._produced(cs, out)
+    assert np.array_equal(be.to_host(out), a)
+    v = be.to_device(np.array([3.5, -1.0]))
+    be._use(cs, v)
+    _ffi.check(lib.npw_allreduce_max_f64(h, v.ptr, 2, cs.handle), "allreduce")
+    be._produced(cs, v)
+    assert np.array_equal(be.to_host(v), [3.5, -1.0])
+    members = (ctypes.c_int * 1)(0)
+    _ffi.check(lib.npw_bcast_tile(h, src.ptr, src.nbytes, 0, members, 1, cs.handle), "bcast")
+    # argument checking
+    assert lib.npw_send_tile(h, src.ptr, 8, 5, cs.handle) == _ffi.NPW_ERR_ARG and b"destination" in lib.npw_last_error()
+    assert lib.npw_comm_init(ctypes.byref(ctypes.c_void_p(0)), 2, 2, ident) == _ffi.NPW_ERR_ARG
+    be.stream_sync(cs)
+    _ffi.check(lib.npw_comm_destroy(h))
+
+
+def test_distributed_executor_over_rccl_world_of_one():
+    """torchrun with one rank: init_process_group() picks the RCCL transport (one device per rank), the distributed
+    executor runs Cholesky / GEMM / TSQR through it."""
+    env = dict(os.environ, DIST_CHECK_N="1024", DIST_CHECK_B="256", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("NUMPYWREN_AMD_STORE", None)
+    env.pop("NUMPYWREN_AMD_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", "29651", os.path.join(ROOT, "tools", "dist_check.py")]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    text = out.stdout + out.stderr
+    assert out.returncode == 0, text[-3000:]
+    assert "dist_check: PASSED" in text and "backend rccl" in text, text[-3000:]

@@ -68,6 +68,7 @@ def _worker(rank, world, port, scenario, outdir):
             assert sum(counts) == int(ntasks)           # every task ran exactly once, somewhere
             assert min(counts) > 0 or int(ntasks) < world
         assert res["bytes_sent"] > 0 or world == 1
+        assert res["headers"] == 0     # every receiver derived shape and dtype from the static plan (TileMetaPlan)
         assert meta["intermediates"][0].block_idxs_exist == []   # reclaim works under sharding
     elif scenario == "tsqr":
         Xh = ALG["tsqr_64_8/X"]
@@ -125,11 +126,24 @@ def _worker(rank, world, port, scenario, outdir):
         scatter_owned(Bb, B, "B")
         program, meta = alg_wrappers.gemm(Ab, Bb)
         program.start()
-        dist.lambdapack_run_distributed(program, comm)
+        res = dist.lambdapack_run_distributed(program, comm)
         assert program.program_status() == lp.PS.SUCCESS, program.exceptions
+        assert res["headers"] == 0 and res["transfers"] > 0     # Temp is safe=False, its tile shapes are still static
         got = dist.gather_matrix(meta["outputs"][0], comm)
         if rank == 0:
             np.testing.assert_allclose(got, C, rtol=1e-12, atol=1e-12)
+    elif scenario == "block_sparse":
+        A = ALG["cholesky_32_8/A"]
+        X = BigMatrix("chol_bs", shape=A.shape, shard_sizes=(8, 8))
+        scatter_owned(X, A, "I")
+        program, meta = alg_wrappers.cholesky(X)
+        program.block_sparse = True
+        program.start()
+        try:
+            dist.lambdapack_run_distributed(program, comm)
+            raise AssertionError("block_sparse must be refused")
+        except NotImplementedError:
+            pass
     elif scenario == "not_pd":
         A = np.eye(32)
         A[20, 20] = -1.0
@@ -174,6 +188,50 @@ def test_gemm_sharded(tmp_path):
 
 def test_failure_reaches_every_rank(tmp_path):
     _spawn(2, "not_pd", tmp_path)
+
+
+def test_block_sparse_is_refused(tmp_path):
+    """an owner that skips a zero tile would leave its consumers waiting in recv."""
+    _spawn(2, "block_sparse", tmp_path)
+
+
+def test_tile_meta_plan_matches_what_the_kernels_produce(oracle_backend):
+    """The static (shape, dtype) table receivers rely on == the tiles a real run stores, for the Cholesky and GEMM
+    programs (fp64 and fp32 inputs, ragged edge blocks)."""
+    import numpy as np
+    from numpywren_amd import alg_wrappers, job_runner
+    from numpywren_amd.dist import TileMetaPlan
+    from numpywren_amd.matrix import BigMatrix
+    from numpywren_amd.matrix_init import shard_matrix
+    rng = np.random.default_rng(0)
+
+    def check(program, meta):
+        compiled = program.program
+        plan = TileMetaPlan(compiled)
+        program.start()
+        job_runner.lambdapack_run(program)
+        n = 0
+        for t in compiled.tasks:
+            outs = plan.visit(t, getattr(compiled.kernel(t.expr_idx), "__name__", ""))
+            assert outs is not None, t.key
+            for (name, idx), m in zip(t.writes, outs):
+                got = compiled.matrices[name].get_tile(*idx)
+                assert int(np.prod(got.shape)) == int(np.prod(m.shape)) and np.dtype(got.dtype) == m.dtype, (t.key, got, m)
+                n += 1
+        return n
+
+    G = rng.standard_normal((40, 40))
+    A = G @ G.T + 40 * np.eye(40)
+    X = BigMatrix("meta_chol", shape=A.shape, shard_sizes=(16, 16))     # 16 + 16 + 8: ragged last block
+    shard_matrix(X, A)
+    assert check(*alg_wrappers.cholesky(X)) == 10
+    for dt in (np.float64, np.float32):
+        Ah, Bh = rng.standard_normal((24, 24)).astype(dt), rng.standard_normal((24, 24)).astype(dt)
+        Am = BigMatrix(f"meta_gA{np.dtype(dt).itemsize}", shape=Ah.shape, shard_sizes=(8, 8), dtype=dt)
+        Bm = BigMatrix(f"meta_gB{np.dtype(dt).itemsize}", shape=Bh.shape, shard_sizes=(8, 8), dtype=dt)
+        shard_matrix(Am, Ah)
+        shard_matrix(Bm, Bh)
+        assert check(*alg_wrappers.gemm(Am, Bm)) > 27
 
 
 def test_process_grid_and_ownership():
