@@ -146,7 +146,8 @@ int npw_comm_destroy(npw_comm_t comm) {
     Comm* c = as_comm(comm);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm != nullptr) (void)g_rccl.CommDestroy(c->comm);
-    (void)hipStreamDestroy(c->stream);
+    // The transport stream is NOT destroyed: tiles that travelled on it remember its handle and record their release
+    // events on it long after the communicator is gone (one idle stream per communicator for the life of the process).
     delete c;
     return NPW_OK;
 }
