@@ -19,6 +19,7 @@
 // cond(L_jj) of the 128-wide block, not of the tile).
 #include "npw_internal.h"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 
@@ -45,6 +46,7 @@ constexpr int LW = 512;
 constexpr int WPG = LW / NB;  // diagonal blocks per group
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2v_t __attribute__((ext_vector_type(2)));  // 16-byte chunk (HIP's double2 struct defeats SROA in register arrays)
 
 
 // ---- cross-lane arithmetic inside a row of 16 lanes (DPP row_newbcast: every lane of the row reads lane K) ----
@@ -829,6 +831,269 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_panel_kernel(int n, double
 #endif
 }
 
+// ================================================================================================
+// Look-ahead block column: ONE launch per 128-wide block column that overlaps the latency-bound chain
+// (diagonal block + panel rows) of column j with the rank-128 trailing update left over from column j-1.
+//
+//   role A  "strips"   (every workgroup, first): block column j itself still lacks the update with panel j-1.  It is cut
+//                      into 16-row strips, one per workgroup (<= 248 for a 4096^2 tile: all run at once),
+//                      C[16 x 128] -= P[strip rows] * P[rows of diagonal block j]^T,  K = 128, one MFMA tile per wave.
+//                      Results are written through (sc1) and announced per 64-row group with one counter increment.
+//   role B  "chain"    (workgroups 0 .. m/64): exactly the fused kernel above -- workgroup 0 factors the diagonal
+//                      block and publishes a message per 16-column step, the others follow with their 64 panel rows
+//                      by substitution -- after the counters of their own rows have reached 4.
+//   role C  "trailing" (every workgroup, when it has nothing else to do): 128 x 128 tiles of the lower triangle right
+//                      of block column j,  C -= P[tile rows] * P[tile cols]^T  with panel j-1, pulled off a ticket
+//                      counter.  This is the 2/3 of the tile's flops; it runs beside the chain instead of after it.
+//
+// With one workgroup per CU (148 KiB of LDS each) all roles of a launch are resident together, which the chain's
+// waits rely on (as potrf_panel_kernel's do); every spin is bounded and a timeout is reported through `info`.
+// Critical path per block column: strips (~4 us) + chain (31 us) + kernel boundary, instead of
+// chain + boundary + trailing GEMM (25 us) + boundary.
+// ================================================================================================
+constexpr int STRIP = 16;                 // rows per look-ahead strip (one MFMA tile row)
+constexpr int STRIPS_PER_GROUP = PGROWS / STRIP;
+constexpr int KC = 32;                    // k chunk of the trailing tiles
+constexpr int TLD = KC + 2;               // LDS row stride of a k chunk (2 * TLD mod 64 == 4: conflict-free b64 columns)
+constexpr int LA_TIMEOUT_INFO = -7777;    // written to *info when a bounded wait expired
+
+__device__ inline void st_through(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// role A: strip `strip` of block column j0 (rows j0 + 16 strip ...), K = 128 panel at columns j0 - 128 .. j0
+__device__ inline void la_strip(double* S, double* A, int64_t lda, int j0, int strip, int* group_cnt) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    double* Bs = S;                    // [128][SLD]  P[rows of the diagonal block], k contiguous
+    double* As = S + NB * SLD;         // [16][SLD]   P[strip rows]
+    const double* Pb = A + (int64_t)j0 * lda + (j0 - NB);
+    const int r0 = j0 + strip * STRIP;
+    const double* Pa = A + (int64_t)r0 * lda + (j0 - NB);
+    double* C = A + (int64_t)r0 * lda + j0;
+    {
+        // all global loads first (one memory round trip), 16-byte chunks
+        constexpr int BCH = NB * NB / 2 / DIAG_THREADS;  // 16
+        d2v_t vb[BCH];
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            const int e = tid + DIAG_THREADS * i;        // chunk id: row = e / 64, chunk = e % 64
+            vb[i] = *reinterpret_cast<const d2v_t*>(Pb + (int64_t)(e >> 6) * lda + 2 * (e & 63));
+        }
+        d2v_t va[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + DIAG_THREADS * i;        // 1024 chunks of the 16 x 128 strip
+            va[i] = *reinterpret_cast<const d2v_t*>(Pa + (int64_t)(e >> 6) * lda + 2 * (e & 63));
+        }
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            const int e = tid + DIAG_THREADS * i;
+            *reinterpret_cast<d2v_t*>(&Bs[(e >> 6) * SLD + 2 * (e & 63)]) = vb[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + DIAG_THREADS * i;
+            *reinterpret_cast<d2v_t*>(&As[(e >> 6) * SLD + 2 * (e & 63)]) = va[i];
+        }
+    }
+    // the product is summed from zero and subtracted once (as the GEMM epilogue does): accumulating into C would
+    // round 32 times at the magnitude of C
+    double cv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cv[r] = C[(int64_t)(lg + 4 * r) * lda + wave * JB + li];
+    d4_t acc = {0, 0, 0, 0};
+    __syncthreads();
+#pragma unroll 8
+    for (int st = 0; st < NB / 4; ++st) {
+        const double a = As[li * SLD + 4 * st + lg];
+        const double b = Bs[(wave * JB + li) * SLD + 4 * st + lg];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st_through(&C[(int64_t)(lg + 4 * r) * lda + wave * JB + li], cv[r] - acc[r]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its stores have been acknowledged
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(&group_cnt[strip / STRIPS_PER_GROUP], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// wait until the strips of the 64-row groups [g0, g1) have all arrived (thread 0 polls; bounded)
+__device__ inline bool la_wait_groups(const int* group_cnt, int g0, int g1, int nstrips, int32_t* info) {
+    __shared__ int ok_flag;
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        for (int g = g0; g < g1; ++g) {
+            const int want = min(STRIPS_PER_GROUP, nstrips - g * STRIPS_PER_GROUP);
+            if (want <= 0) break;
+            int spin = 0;
+            while (__hip_atomic_load(&group_cnt[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spin > (1 << 22)) {
+                    ok = 0;
+                    break;
+                }
+            }
+            if (!ok) break;
+        }
+        if (!ok) atomicCAS(info, 0, LA_TIMEOUT_INFO);
+        ok_flag = ok;
+    }
+    __syncthreads();
+    return ok_flag != 0;
+}
+
+// role C: one 128 x 128 tile of the trailing update with the K = 128 panel at columns pc .. pc + 128:
+//   C[rm .. rm+128, cn .. cn+128] -= A[rm .., pc ..] * A[cn .., pc ..]^T        (rm, cn: absolute row / column)
+// 8 waves as 4 x 2, wave tile 32 x 64; k in four chunks of 32 through a double-buffered LDS stage (one barrier per
+// chunk), the next chunk's global loads in flight while the current one is multiplied.
+__device__ inline void la_tile(double* S, double* A, int64_t lda64, int pc, int rm, int cn) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;
+    constexpr int STAGE = 2 * NB * TLD;              // [A chunk | B chunk], each [128][TLD]
+    const double* Pa = A + (int64_t)rm * lda64 + pc;
+    const double* Pb = A + (int64_t)cn * lda64 + pc;
+    double* C = A + (int64_t)rm * lda64 + cn;
+    constexpr int CH = NB * KC / 2 / DIAG_THREADS;   // 4 16-byte chunks per thread and operand
+    const int grow = tid >> 4, gcol = 2 * (tid & 15);  // chunk i of this thread: row grow + 32 i, columns gcol, gcol + 1
+    const int loff = grow * TLD + gcol;
+    d2v_t ra[CH], rb[CH];
+    const double* pa = Pa + (int64_t)grow * lda64 + gcol;
+    const double* pb = Pb + (int64_t)grow * lda64 + gcol;
+#define LA_GLOAD(kc)                                                                   \
+    _Pragma("unroll") for (int i = 0; i < CH; ++i) {                                   \
+        ra[i] = *reinterpret_cast<const d2v_t*>(pa + (int64_t)(32 * i) * lda64 + (kc)); \
+        rb[i] = *reinterpret_cast<const d2v_t*>(pb + (int64_t)(32 * i) * lda64 + (kc)); \
+    }
+#define LA_LSTORE(buf)                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < CH; ++i) {                                                   \
+        *reinterpret_cast<d2v_t*>(&S[(buf) * STAGE + loff + i * 32 * TLD]) = ra[i];                  \
+        *reinterpret_cast<d2v_t*>(&S[(buf) * STAGE + NB * TLD + loff + i * 32 * TLD]) = rb[i];       \
+    }
+    LA_GLOAD(0)
+    // one pointer per accumulator row (8 of them), the column block j as an immediate offset
+    double* const c0 = C + (int64_t)(wm0 + lg) * lda64 + (wn0 + li);
+    d4_t acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+    __syncthreads();               // the previous user of S is done
+    LA_LSTORE(0)
+    __syncthreads();
+    const int aoff = (wm0 + li) * TLD + lg, boff = NB * TLD + (wn0 + li) * TLD + lg;
+#pragma unroll
+    for (int c = 0; c < NB / KC; ++c) {
+        if (c + 1 < NB / KC) {
+            LA_GLOAD((c + 1) * KC)
+        }
+        const double* Sc = S + (c & 1) * STAGE;
+#pragma unroll
+        for (int st = 0; st < KC / 4; ++st) {
+            double a[2], b[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = Sc[aoff + 16 * i * TLD + 4 * st];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Sc[boff + 16 * j * TLD + 4 * st];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (c + 1 < NB / KC) {
+            LA_LSTORE((c + 1) & 1)
+        }
+        __syncthreads();
+    }
+#undef LA_GLOAD
+#undef LA_LSTORE
+    // C - product, the product summed from zero (one rounding at the magnitude of C, as in the GEMM epilogue)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        double cv[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double* crow = c0 + (int64_t)(16 * i + 4 * r) * lda64;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cv[r][j] = crow[16 * j];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double* crow = c0 + (int64_t)(16 * i + 4 * r) * lda64;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) crow[16 * j] = cv[r][j] - acc[i][j][r];
+        }
+    }
+}
+
+// ctl: [0] = ticket counter of role C, [1 ..] = arrival counters of the 64-row groups of block column j0 (zeroed by the host)
+__global__ __launch_bounds__(DIAG_THREADS) void potrf_step_kernel(int N, double* A, int64_t lda, int j0, int32_t* info,
+                                                                  double* Wj, pslot_t* msg, unsigned long long msg_tag, int* ctl) {
+    extern __shared__ __attribute__((aligned(16))) double S[];
+    __shared__ int s_ticket;
+    const int m_below = N - j0 - NB;                        // rows below the diagonal block
+    const int chain_wgs = 1 + (m_below + PGROWS - 1) / PGROWS;
+    const int nstrips = (j0 > 0) ? (N - j0) / STRIP : 0;
+    int* group_cnt = ctl + 1;
+    // ---- role A ----
+    for (int sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+        __syncthreads();
+        la_strip(S, A, lda, j0, sidx, group_cnt);
+    }
+    // ---- role B ----
+    if ((int)blockIdx.x < chain_wgs) {
+        bool ok = true;
+        if (nstrips > 0) {
+            const int g0 = (blockIdx.x == 0) ? 0 : (int)blockIdx.x + 1;
+            const int g1 = (blockIdx.x == 0) ? NB / PGROWS : g0 + 1;
+            ok = la_wait_groups(group_cnt, g0, g1, nstrips, info);
+        }
+        __syncthreads();
+        double* Ajj = A + (int64_t)j0 * lda + j0;
+        if (blockIdx.x == 0) {
+            if (ok) {
+                diag_block(NB, Ajj, lda, info, j0, Wj, S, false, msg, msg_tag);
+            } else {
+                // release the panel workgroups (zero messages): the matrix is reported as failed through info
+                for (int k = 0; k < NJB; ++k) {
+                    pslot_fwd_t x;
+                    x[0] = 0.0;
+                    x[1] = __longlong_as_double((long long)(msg_tag + k));
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(msg + (size_t)k * 2 * JB * JB + threadIdx.x), "v"(x) : "memory");
+                }
+            }
+        } else {
+            const int r0 = ((int)blockIdx.x - 1) * PGROWS;
+            double* P = Ajj + (int64_t)(NB + r0) * lda;
+            panel_rows_prog(S, P, lda, min(PGROWS, m_below - r0), Ajj, msg, msg_tag);
+        }
+    }
+    // ---- role C ----
+    if (j0 > 0 && m_below > 0) {
+        const int t = m_below / NB;                         // tile rows / columns right of block column j0
+        const int ntiles = t * (t + 1) / 2;
+        for (;;) {
+            __syncthreads();
+            if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const int id = __builtin_amdgcn_readfirstlane(s_ticket);   // uniform: keeps the tile's base addresses scalar
+            if (id >= ntiles) break;
+            // column-major walk of the lower triangle: the tall left columns first
+            int tn = 0, rem = id;
+            while (rem >= t - tn) {
+                rem -= t - tn;
+                ++tn;
+            }
+            const int tm = tn + rem;
+            la_tile(S, A, lda, j0 - NB, j0 + NB + tm * NB, j0 + NB + tn * NB);
+        }
+    }
+}
+
 // Batched inversion of the NB x NB diagonal blocks of the n x n lower-triangular L:
 // block b -> Winv + w_block_offset(b), ld = LW.
 __global__ __launch_bounds__(DIAG_THREADS) void trtri_diag_kernel(int n, const double* L, int64_t ldl,
@@ -1014,6 +1279,52 @@ int potrf_right(int64_t n, double* A, int64_t lda, int32_t* info, double* Winv, 
     return NPW_OK;
 }
 
+// Right-looking factorisation with look-ahead: one potrf_step_kernel launch per block column (see above).
+// n must be a multiple of NB with at most 256 chain workgroups.  ctl lives behind the messages in Winv's scratch.
+bool lookahead_applies(int64_t n) {
+    static const bool off = getenv("NPW_POTRF_NO_LOOKAHEAD") != nullptr;
+    return !off && n % NB == 0 && n >= 2 * NB && n <= 8192;
+}
+constexpr int CTL_INTS = 1 + 8192 / PGROWS + 8;   // per block column: ticket + group counters
+
+int potrf_lookahead(int64_t n, double* A, int64_t lda, int32_t* info, double* Winv, hipStream_t s) {
+    pslot_t* msg = reinterpret_cast<pslot_t*>(Winv + winv_group_elems(n));
+    int* ctl = reinterpret_cast<int*>(msg + (size_t)NJB * MSG_SLOTS);
+    const int64_t steps = n / NB;
+    NPW_HIP_CHECK(hipMemsetAsync(ctl, 0, (size_t)steps * CTL_INTS * sizeof(int), s));
+    static std::atomic<unsigned long long> call_counter{
+        (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() & 0x3fffffffULL};
+    const unsigned long long call_tag = (call_counter.fetch_add(1) + 1) << 20;
+    static const int num_cus = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }();
+    for (int64_t jb = 0; jb < steps; ++jb) {
+        const int64_t j0 = jb * NB;
+        const int64_t m = n - j0 - NB;
+        const unsigned chain = 1 + (unsigned)ceil_div(m, PGROWS);
+        // every role of a launch must be resident at once: never more workgroups than CUs (each needs a whole CU's LDS)
+        unsigned wgs = chain;
+        if (jb > 0) {
+            const unsigned strips = (unsigned)((n - j0) / STRIP);
+            const int64_t t = m / NB;
+            const unsigned tiles = (unsigned)(t * (t + 1) / 2);
+            wgs = std::max(wgs, std::min<unsigned>(std::max(strips, chain + tiles), (unsigned)num_cus));
+        }
+        NPW_REQUIRE(chain <= (unsigned)num_cus, "potrf: block column needs %u resident workgroups, device has %d CUs", chain, num_cus);
+        hipLaunchKernelGGL(potrf_step_kernel, dim3(wgs), dim3(DIAG_THREADS), DIAG_LDS_BYTES, s, (int)n, A, lda, (int)j0, info,
+                           Winv + w_block_offset(jb), msg, call_tag + (unsigned long long)jb * NJB + 1, ctl + jb * CTL_INTS);
+        NPW_LAUNCH_CHECK();
+    }
+    // the last panel's trailing update never ran as role C of a following launch: the last block column has nothing
+    // right of it, so nothing is left -- but block column steps-1 still needs ITS strips, which its own launch did.
+    hipLaunchKernelGGL(trtri_diag_kernel, dim3((unsigned)steps), dim3(DIAG_THREADS), DIAG_LDS_BYTES, s, (int)n, A, lda, Winv);
+    NPW_LAUNCH_CHECK();
+    return NPW_OK;
+}
+
 int ensure_big_lds() {
     static thread_local bool attr = false;
     if (!attr) {
@@ -1022,6 +1333,8 @@ int ensure_big_lds() {
         rc = set_big_lds(reinterpret_cast<const void*>(potrf_diag_kernel));
         if (rc) return rc;
         rc = set_big_lds(reinterpret_cast<const void*>(potrf_panel_kernel));
+        if (rc) return rc;
+        rc = set_big_lds(reinterpret_cast<const void*>(potrf_step_kernel));
         if (rc) return rc;
         attr = true;
     }
@@ -1120,7 +1433,7 @@ int npw_dpotrf_lower(int64_t n, const double* A, int64_t lda, double* Lout, int6
     }
     double* Winv = static_cast<double*>(workspace);
     NPW_HIP_CHECK(hipMemsetAsync(Winv, 0, winv_group_elems(n) * sizeof(double), s));
-    rc = potrf_right(n, Lout, ldl, info_dev, Winv, s);
+    rc = lookahead_applies(n) ? potrf_lookahead(n, Lout, ldl, info_dev, Winv, s) : potrf_right(n, Lout, ldl, info_dev, Winv, s);
     if (rc) return rc;
     return complete_groups(n, Lout, ldl, Winv, s);  // the factor's trsm consumers use LW-wide leaves
 }
