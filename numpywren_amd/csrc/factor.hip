@@ -854,7 +854,6 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_panel_kernel(int n, double
 constexpr int STRIP = 16;                 // rows per look-ahead strip (one MFMA tile row)
 constexpr int STRIPS_PER_GROUP = PGROWS / STRIP;
 constexpr int KC = 32;                    // k chunk of the trailing tiles
-constexpr int TLD = KC + 2;               // LDS row stride of a k chunk (2 * TLD mod 64 == 4: conflict-free b64 columns)
 constexpr int LA_TIMEOUT_INFO = -7777;    // written to *info when a bounded wait expired
 
 __device__ inline void st_through(double* p, double v) {
@@ -943,98 +942,159 @@ __device__ inline bool la_wait_groups(const int* group_cnt, int g0, int g1, int 
     return ok_flag != 0;
 }
 
-// role C: one 128 x 128 tile of the trailing update with the K = 128 panel at columns pc .. pc + 128:
-//   C[rm .. rm+128, cn .. cn+128] -= A[rm .., pc ..] * A[cn .., pc ..]^T        (rm, cn: absolute row / column)
-// 8 waves as 4 x 2, wave tile 32 x 64; k in four chunks of 32 through a double-buffered LDS stage (one barrier per
-// chunk), the next chunk's global loads in flight while the current one is multiplied.
-__device__ inline void la_tile(double* S, double* A, int64_t lda64, int pc, int rm, int cn) {
+// role C: the trailing update with the K = 128 panel at columns pc .. pc + 128, as 128 x 128 tiles of the lower
+// triangle of the t x t tile grid whose corner is (base, base):
+//   C[rm .. rm+128, cn .. cn+128] -= A[rm .., pc ..] * A[cn .., pc ..]^T
+// pulled off a ticket counter until it runs dry.  8 waves as 4 x 2, wave tile 32 x 64; k in four chunks of 32 through
+// a double-buffered LDS stage (one barrier per chunk).  One workgroup per CU means nobody else covers this
+// workgroup's memory phases, so the loop is software-pipelined ACROSS tiles: the next ticket is drawn at the start of
+// a tile, the next tile's first k chunk is loaded during the last chunk's products, and the tile's own C values are
+// fetched one chunk before they are needed -- the matrix pipes only idle for the LDS stores between chunks.
+__device__ inline void la_trailing(double* S, double* A, int64_t lda64, int pc, int base, int t, int* ticket_ctr) {
+    __shared__ int s_next[2];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
     const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;
-    constexpr int STAGE = 2 * NB * TLD;              // [A chunk | B chunk], each [128][TLD]
-    const double* Pa = A + (int64_t)rm * lda64 + pc;
-    const double* Pb = A + (int64_t)cn * lda64 + pc;
-    double* C = A + (int64_t)rm * lda64 + cn;
+    constexpr int STAGE = 2 * NB * KC;               // [A chunk | B chunk], each [128][KC] with XOR-swizzled 16-byte chunks
     constexpr int CH = NB * KC / 2 / DIAG_THREADS;   // 4 16-byte chunks per thread and operand
+    const int ntiles = t * (t + 1) / 2;
     const int grow = tid >> 4, gcol = 2 * (tid & 15);  // chunk i of this thread: row grow + 32 i, columns gcol, gcol + 1
-    const int loff = grow * TLD + gcol;
+    // LDS element offset of (row, 16-byte chunk c) inside an operand's [128][KC] block: rows are unpadded and the chunk
+    // index is XORed with the row number (gemm.hip's kc_off for 16 chunks per row): a fragment for TWO k steps is one
+    // conflict-free ds_read_b128 (lane group lg, step pair p: k = 8 p + 2 lg + {0, 1} -- any k order works as long as
+    // both operands use the same one), and the 16-byte stores of the staging copy are conflict-free as well.
+    auto sw = [](int row, int chunk) { return row * KC + ((chunk ^ (row & 15)) << 1); };
+    const int64_t goff = (int64_t)grow * lda64 + gcol;
+    const int64_t coff = (int64_t)(wm0 + lg) * lda64 + (wn0 + li);
+    // column-major walk of the lower triangle (the tall left columns first): ticket -> absolute (row, column)
+    auto tile_of = [&](int id, int& rm, int& cn) {
+        int tn = 0, rem = id;
+        while (rem >= t - tn) {
+            rem -= t - tn;
+            ++tn;
+        }
+        rm = base + (tn + rem) * NB;
+        cn = base + tn * NB;
+    };
+    __syncthreads();               // the previous user of S is done
+    if (tid == 0) s_next[0] = __hip_atomic_fetch_add(ticket_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    int id = __builtin_amdgcn_readfirstlane(s_next[0]);
+    if (id >= ntiles) return;
+    int rm, cn;
+    tile_of(id, rm, cn);
+    const double* pa = A + (int64_t)rm * lda64 + pc + goff;
+    const double* pb = A + (int64_t)cn * lda64 + pc + goff;
     d2v_t ra[CH], rb[CH];
-    const double* pa = Pa + (int64_t)grow * lda64 + gcol;
-    const double* pb = Pb + (int64_t)grow * lda64 + gcol;
-#define LA_GLOAD(kc)                                                                   \
-    _Pragma("unroll") for (int i = 0; i < CH; ++i) {                                   \
+#define LA_GLOAD(kc)                                                                    \
+    _Pragma("unroll") for (int i = 0; i < CH; ++i) {                                    \
         ra[i] = *reinterpret_cast<const d2v_t*>(pa + (int64_t)(32 * i) * lda64 + (kc)); \
         rb[i] = *reinterpret_cast<const d2v_t*>(pb + (int64_t)(32 * i) * lda64 + (kc)); \
     }
-#define LA_LSTORE(buf)                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < CH; ++i) {                                                   \
-        *reinterpret_cast<d2v_t*>(&S[(buf) * STAGE + loff + i * 32 * TLD]) = ra[i];                  \
-        *reinterpret_cast<d2v_t*>(&S[(buf) * STAGE + NB * TLD + loff + i * 32 * TLD]) = rb[i];       \
+#define LA_LSTORE(buf)                                                                            \
+    _Pragma("unroll") for (int i = 0; i < CH; ++i) {                                              \
+        *reinterpret_cast<d2v_t*>(&S[(buf) * STAGE + sw(grow + 32 * i, tid & 15)]) = ra[i];           \
+        *reinterpret_cast<d2v_t*>(&S[(buf) * STAGE + NB * KC + sw(grow + 32 * i, tid & 15)]) = rb[i]; \
     }
     LA_GLOAD(0)
-    // one pointer per accumulator row (8 of them), the column block j as an immediate offset
-    double* const c0 = C + (int64_t)(wm0 + lg) * lda64 + (wn0 + li);
-    d4_t acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
-    __syncthreads();               // the previous user of S is done
     LA_LSTORE(0)
-    __syncthreads();
-    const int aoff = (wm0 + li) * TLD + lg, boff = NB * TLD + (wn0 + li) * TLD + lg;
+    int slot = 0;
+    for (;;) {
+        double* const c0 = A + (int64_t)rm * lda64 + cn + coff;   // one pointer per accumulator row, column blocks as immediates
+        __syncthreads();           // stage 0 of this tile is in LDS; everybody is done with the previous tile's stages
+        d4_t acc[2][4];
 #pragma unroll
-    for (int c = 0; c < NB / KC; ++c) {
-        if (c + 1 < NB / KC) {
-            LA_GLOAD((c + 1) * KC)
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+        double cv[2][4][4];
+        int nid = ntiles, ticket = 0;
+#pragma unroll
+        for (int c = 0; c < NB / KC; ++c) {
+            // the next ticket: drawn while nothing of this wave's is in flight but k chunks (a returning atomic drains
+            // the wave's memory queue), parked in a register for a chunk, published through LDS before the last chunk
+            if (c == 1 && tid == 0) ticket = __hip_atomic_fetch_add(ticket_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c + 1 < NB / KC) {
+                LA_GLOAD((c + 1) * KC)
+            } else {
+                nid = __builtin_amdgcn_readfirstlane(s_next[slot ^ 1]);
+                if (nid < ntiles) {
+                    tile_of(nid, rm, cn);
+                    pa = A + (int64_t)rm * lda64 + pc + goff;
+                    pb = A + (int64_t)cn * lda64 + pc + goff;
+                    LA_GLOAD(0)
+                }
+            }
+            if (c == NB / KC - 2) {
+                if (tid == 0) s_next[slot ^ 1] = ticket;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double* crow = c0 + (int64_t)(16 * i + 4 * r) * lda64;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) cv[i][r][j] = crow[16 * j];
+                    }
+            }
+            const double* Sc = S + (c & 1) * STAGE;
+            // fragments of step pair p + 1 are fetched while pair p is multiplied
+            d2v_t af[2][2], bf[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[0][i] = *reinterpret_cast<const d2v_t*>(&Sc[sw(wm0 + 16 * i + li, lg)]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[0][j] = *reinterpret_cast<const d2v_t*>(&Sc[NB * KC + sw(wn0 + 16 * j + li, lg)]);
+#pragma unroll
+            for (int pr = 0; pr < KC / 8; ++pr) {
+                if (pr + 1 < KC / 8) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        af[(pr + 1) & 1][i] = *reinterpret_cast<const d2v_t*>(&Sc[sw(wm0 + 16 * i + li, 4 * (pr + 1) + lg)]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        bf[(pr + 1) & 1][j] = *reinterpret_cast<const d2v_t*>(&Sc[NB * KC + sw(wn0 + 16 * j + li, 4 * (pr + 1) + lg)]);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[pr & 1][i][h], bf[pr & 1][j][h], acc[i][j], 0, 0, 0);
+            }
+            if (c + 1 < NB / KC) {
+                LA_LSTORE((c + 1) & 1)
+                __syncthreads();
+            }
         }
-        const double* Sc = S + (c & 1) * STAGE;
-#pragma unroll
-        for (int st = 0; st < KC / 4; ++st) {
-            double a[2], b[4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = Sc[aoff + 16 * i * TLD + 4 * st];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = Sc[boff + 16 * j * TLD + 4 * st];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        // the next tile's first chunk goes to stage 0 (last read two barriers ago) BEFORE this tile's stores are issued:
+        // a wait for those loads placed behind the stores would wait for the stores as well
+        if (nid < ntiles) {
+            LA_LSTORE(0)
         }
-        if (c + 1 < NB / KC) {
-            LA_LSTORE((c + 1) & 1)
-        }
-        __syncthreads();
+        // C - product, the product summed from zero (one rounding at the magnitude of C, as in the GEMM epilogue)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double* crow = c0 + (int64_t)(16 * i + 4 * r) * lda64;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) crow[16 * j] = cv[i][r][j] - acc[i][j][r];
+            }
+        if (nid >= ntiles) break;
+        id = nid;
+        slot ^= 1;
     }
 #undef LA_GLOAD
 #undef LA_LSTORE
-    // C - product, the product summed from zero (one rounding at the magnitude of C, as in the GEMM epilogue)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        double cv[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double* crow = c0 + (int64_t)(16 * i + 4 * r) * lda64;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) cv[r][j] = crow[16 * j];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            double* crow = c0 + (int64_t)(16 * i + 4 * r) * lda64;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) crow[16 * j] = cv[r][j] - acc[i][j][r];
-        }
-    }
 }
 
 // ctl: [0] = ticket counter of role C, [1 ..] = arrival counters of the 64-row groups of block column j0 (zeroed by the host)
 __global__ __launch_bounds__(DIAG_THREADS) void potrf_step_kernel(int N, double* A, int64_t lda, int j0, int32_t* info,
                                                                   double* Wj, pslot_t* msg, unsigned long long msg_tag, int* ctl) {
     extern __shared__ __attribute__((aligned(16))) double S[];
-    __shared__ int s_ticket;
     const int m_below = N - j0 - NB;                        // rows below the diagonal block
     const int chain_wgs = 1 + (m_below + PGROWS - 1) / PGROWS;
     const int nstrips = (j0 > 0) ? (N - j0) / STRIP : 0;
@@ -1073,25 +1133,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_step_kernel(int N, double*
         }
     }
     // ---- role C ----
-    if (j0 > 0 && m_below > 0) {
-        const int t = m_below / NB;                         // tile rows / columns right of block column j0
-        const int ntiles = t * (t + 1) / 2;
-        for (;;) {
-            __syncthreads();
-            if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            const int id = __builtin_amdgcn_readfirstlane(s_ticket);   // uniform: keeps the tile's base addresses scalar
-            if (id >= ntiles) break;
-            // column-major walk of the lower triangle: the tall left columns first
-            int tn = 0, rem = id;
-            while (rem >= t - tn) {
-                rem -= t - tn;
-                ++tn;
-            }
-            const int tm = tn + rem;
-            la_tile(S, A, lda, j0 - NB, j0 + NB + tm * NB, j0 + NB + tn * NB);
-        }
-    }
+    if (j0 > 0 && m_below > 0) la_trailing(S, A, lda, j0 - NB, j0 + NB, m_below / NB, &ctl[0]);
 }
 
 // Batched inversion of the NB x NB diagonal blocks of the n x n lower-triangular L:
