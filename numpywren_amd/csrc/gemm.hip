@@ -112,18 +112,23 @@ struct GemmParams {
     int64_t batch2_a, batch2_b, batch2_c, batch2_d;
     int b_lower_tri;                                  // k range of column tile n0 ends at n0 + BN
     int k_from_diag;                                  // k range of tile (m0, n0) starts at max(m0, n0) (trapezoidal operands)
+    int a_upper_tri;                                  // k range of row tile m0 starts at m0 (op(A) upper triangular)
 };
 
 // XCD-aware + grouped mapping of the linear block id to an output tile.
 // Blocks are dispatched round-robin over the 8 XCDs (observed; speed only): give each XCD a
 // contiguous range of the tile sequence, and order the sequence in GROUP-row bands walked
 // column-major so concurrently running blocks share A row-panels and B column-panels.
-__device__ inline void block_to_tile(int tiles_m, int tiles_n, int& tm, int& tn) {
+__device__ inline void block_to_tile(int tiles_m, int tiles_n, bool spread, int& tm, int& tn) {
     const int nwg = tiles_m * tiles_n;
     const int b = blockIdx.x;
     constexpr int NXCD = 8;
     int id;
-    {
+    if (spread) {
+        // tiles of unequal length (triangular operands: the k range depends on the tile's row or column): a contiguous
+        // run per XCD would hand one XCD all the long tiles; consecutive ids go to consecutive XCDs instead
+        id = b;
+    } else {
         const int q = nwg / NXCD, r = nwg % NXCD;
         const int xcd = b % NXCD, within = b / NXCD;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
@@ -141,13 +146,13 @@ __device__ inline void block_to_tile(int tiles_m, int tiles_n, int& tm, int& tn)
 // workgroups, every XCD gets a contiguous, equally long run of the row-major triangle.  (With the
 // rectangular mapping + early exit the XCD that owns the bottom tile rows does several times the work of
 // the one that owns the top rows, and the launch takes as long as the full square.)
-__device__ inline void block_to_tile_tri(int tiles, int& tm, int& tn) {
+__device__ inline void block_to_tile_tri(int tiles, bool spread, int& tm, int& tn) {
     const int nwg = tiles * (tiles + 1) / 2;
     const int b = blockIdx.x;
     constexpr int NXCD = 8;
     const int q = nwg / NXCD, r = nwg % NXCD;
     const int xcd = b % NXCD, within = b / NXCD;
-    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    const int id = spread ? b : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
     int row = (int)((sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
     while ((row + 1) * (row + 2) / 2 <= id) ++row;
     while (row * (row + 1) / 2 > id) --row;
@@ -198,13 +203,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
     constexpr int STAGE = A_ELEMS + B_ELEMS;
 
     int tile_m, tile_n;
+    // (only when the launch takes several rounds of workgroups: within one round everybody is resident anyway and the
+    //  contiguous map's L2 locality is worth more)
+    const bool spread = (p.b_lower_tri || p.k_from_diag || p.a_upper_tri) && (gridDim.x * gridDim.y * gridDim.z > 1024u);
     if (p.lower_only == 2) {
-        block_to_tile_tri(p.tiles_m, tile_m, tile_n);
+        block_to_tile_tri(p.tiles_m, spread, tile_m, tile_n);
     } else if (p.lower_only == 3) {  // strictly lower tiles: the triangle of order tiles - 1, one row down
-        block_to_tile_tri(p.tiles_m - 1, tile_m, tile_n);
+        block_to_tile_tri(p.tiles_m - 1, spread, tile_m, tile_n);
         tile_m += 1;
     } else {
-        block_to_tile(p.tiles_m, p.tiles_n, tile_m, tile_n);
+        block_to_tile(p.tiles_m, p.tiles_n, spread, tile_m, tile_n);
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     if (p.lower_only && n0 > m0 + BM - 1) return;  // tile entirely above the diagonal
@@ -218,6 +226,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
     // split-K: blockIdx.y selects the k range [kb, kend) and its own partial output
     int kb = p.k_chunk > 0 ? (int)blockIdx.y * p.k_chunk : 0;
     if (p.k_from_diag) kb = max(kb, (max(m0, n0) / BK) * BK);  // V^T V with V lower trapezoidal: rows above are zero
+    if (p.a_upper_tri) kb = max(kb, (m0 / BK) * BK);           // T1 * X with T1 upper triangular: columns left of the diagonal are zero
     int kend = p.k_chunk > 0 ? min(p.K, kb + p.k_chunk) : p.K;
     if (p.b_lower_tri) kend = min(kend, n0 + BN);  // rows of W^T below the diagonal block are zero
     int nk = (kend - kb + BK - 1) / BK;
@@ -642,6 +651,7 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
     p.batch2_d = opts.batch2_d;
     p.b_lower_tri = opts.b_lower_tri ? 1 : 0;
     p.k_from_diag = opts.k_from_diag ? 1 : 0;
+    p.a_upper_tri = opts.a_upper_tri ? 1 : 0;
     p.tag = opts.tag;
     p.k_chunk = opts.k_chunk_;
     p.split_stride = opts.k_chunk_ > 0 ? m * n : 0;

@@ -64,6 +64,7 @@ struct GemmOpts {
     int64_t batch2_a = 0, batch2_b = 0, batch2_c = 0, batch2_d = 0;
     bool b_lower_tri = false;  // op(B) = W^T with W (n x k) lower triangular: column tile n0 only needs k < n0 + BN
     bool k_from_diag = false;  // op(A)^T, op(B) (k x m, k x n) lower trapezoidal: tile (m0, n0) only needs k >= max(m0, n0)
+    bool a_upper_tri = false;  // op(A) (m x k) upper triangular: row tile m0 only needs k >= m0
 };
 
 // D = alpha * op(A) op(B) + beta * C

@@ -394,13 +394,17 @@ int merge_t(const Batch& b, int64_t lo, int64_t hi, int64_t leaf, double* T, int
     rc = merge_t(b, mid, hi, leaf, T, ldt, G, ldg, sG, g0, Tmp, sTmp, s);
     if (rc) return rc;
     const int64_t w1 = mid - lo, w2 = hi - mid;
-    // Tmp (w1 x w2) = G12 * T2 = G21^T * T2
+    // Tmp (w1 x w2) = G12 * T2 = G21^T * T2;  T2 is upper triangular: column tile n0 of the product only sums k < n0 + tile
+    GemmOpts o1 = batched(b, sG, b.sT, 0, sTmp);
+    o1.b_lower_tri = true;
     rc = gemm<double>('T', 'N', w1, w2, w2, 1.0, G + (mid - g0) * ldg + (lo - g0), ldg, T + mid * ldt + mid, ldt, 0.0,
-                      nullptr, 0, Tmp, w2, batched(b, sG, b.sT, 0, sTmp), s);
+                      nullptr, 0, Tmp, w2, o1, s);
     if (rc) return rc;
-    // T12 = -T1 * Tmp
+    // T12 = -T1 * Tmp;  T1 is upper triangular: row tile m0 only sums k >= m0   (together: half the flops of the merge)
+    GemmOpts o2 = batched(b, b.sT, sTmp, 0, b.sT);
+    o2.a_upper_tri = true;
     return gemm<double>('N', 'N', w1, w2, w1, -1.0, T + lo * ldt + lo, ldt, Tmp, w2, 0.0, nullptr, 0,
-                        T + lo * ldt + mid, ldt, batched(b, b.sT, sTmp, 0, b.sT), s);
+                        T + lo * ldt + mid, ldt, o2, s);
 }
 
 // The top `rows` rows of the updated columns are final rows of R: move them to R and clear them in the working matrix
