@@ -279,6 +279,15 @@ int npw_fill_random(double* A, int64_t rows, int64_t cols, int64_t lda, uint64_t
 int npw_dsumsq(const double* A, int64_t rows, int64_t cols, int64_t lda, double* out_dev,
                npw_stream_t stream);
 
+/* Reduction of the n x n block A (overwritten) to upper bidiagonal form B = Q^T A P by Householder
+ * reflections from both sides (LAPACK DGEBD2 order, DLARFG signs): d[0..n) = diagonal, e[0..n-1) =
+ * superdiagonal of B; Q and P are not formed.  The arithmetic of kernels.banded_to_bidiagonal
+ * (reference numpywren/kernels.py:43-65: DGBBRD with vect = 'N' on a band-packed list of s x s
+ * diagonal blocks -- a block-diagonal matrix, so every block is reduced on its own and, P keeping e_1,
+ * its bidiagonal form is unique up to the signs of d_i, e_i).  workspace: npw_dgebd2_workspace_bytes(n). */
+size_t npw_dgebd2_workspace_bytes(int64_t n);
+int npw_dgebd2(int64_t n, double* A, int64_t lda, double* d, double* e, void* workspace, npw_stream_t stream);
+
 /* ---- tile transport between the GPUs of one node: RCCL over xGMI --------------------
  * Replaces the reference's only way to move a tile from one worker to another: an S3 PUT
  * by the producer and an S3 GET by every consumer (reference numpywren/matrix.py:508

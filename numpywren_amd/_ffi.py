@@ -92,6 +92,8 @@ PROTOTYPES = {
     "npw_fill_outer": (c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, c_double, _vp]),
     "npw_fill_random": (c_int, [_vp, _i64, _i64, _i64, c_uint64, _i64, _i64, _vp]),
     "npw_dsumsq": (c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "npw_dgebd2_workspace_bytes": (_sz, [_i64]),
+    "npw_dgebd2": (c_int, [_i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "npw_comm_unique_id": (c_int, [_vp, _sz]),
     "npw_comm_init": (c_int, [POINTER(_vp), c_int, c_int, _vp]),
     "npw_comm_destroy": (c_int, [_vp]),

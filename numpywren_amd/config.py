@@ -16,8 +16,10 @@ DEFAULTS = {
         "exact_zero_shortcircuit": True,  # reproduce the reference's allclose(x, 0) early-outs
         "reclaim_intermediates": False,   # free intermediate tiles after their last reader
         # Ready tasks of one latency-bound kind (qr_factor: the TSQR leaves, the nodes of a tree level) that are
-        # handed to the device as a single batched launch sequence; 1 = one task at a time.
-        "batch_tasks": 16,
+        # handed to the device as a single batched launch sequence; 1 = one task at a time.  32 = what the QR panel kernel
+        # holds at once for 4096-row tiles (2 workgroups per CU x 256 CUs / 16 slabs); 128-leaf TSQR: 1046 ms with 16,
+        # 949 ms with 32 (profiles/r02_qr_tsqr.md).
+        "batch_tasks": 32,
     },
     "store": {
         "tier": "hbm",           # "hbm" (device memory) or "host" (pinned/pageable host memory)

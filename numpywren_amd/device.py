@@ -992,6 +992,22 @@ class HipBackend(object):
             r.upper = True
         return out
 
+    def gebd2(self, A, stream=None):
+        """(d, e) of the upper bidiagonal form of the square fp64 tile A (npw_dgebd2; A is not modified)."""
+        self._require_2d(A, "banded_to_bidiagonal")
+        sh = self._sh(stream)
+        n = A.shape[0]
+        if A.shape[1] != n:
+            raise ValueError(f"banded_to_bidiagonal: blocks must be square, got {A.shape}")
+        work = self.copy(self.as_f64(A, sh), sh)
+        d, e = self.empty((n,), _F64), self.empty((max(n - 1, 0),), _F64)
+        ws = self.alloc(max(16, self.lib.npw_dgebd2_workspace_bytes(n)))
+        ws.streams.add(sh)
+        self._use(sh, work, d, e)
+        _ffi.check(self.lib.npw_dgebd2(n, work.ptr, n, d.ptr, e.ptr if n > 1 else None, ws.ptr, sh), "gebd2")
+        self._produced(sh, d, e)
+        return d, e
+
     def tri(self, tile, uplo, unit_diag=False, stream=None):
         """np.triu / np.tril of a 2-D fp64 tile as a new tile; unit_diag forces ones on the diagonal."""
         self._require_2d(tile, "tri")

@@ -81,7 +81,7 @@ class LambdaPackExecutor(object):
         cfg = (program.config or {}).get("executor", {}) if isinstance(program.config, dict) else {}
         self.exact_zero = cfg.get("exact_zero_shortcircuit", True) if exact_zero is None else exact_zero
         self.reclaim = cfg.get("reclaim_intermediates", False)
-        self.batch_tasks = max(1, int(cfg.get("batch_tasks", 16)))
+        self.batch_tasks = max(1, int(cfg.get("batch_tasks", 32)))
         pool = getattr(self.be, "bulk_streams", None) or self.be.streams
         n = max(1, min(int(pipeline_width), len(pool)))
         self.streams = pool[:n]

@@ -452,8 +452,47 @@ qr_factor_triangular._npw_batch = _qr_factor_triangular_batch
 
 
 def banded_to_bidiagonal(x):
-    raise NotImplementedError("banded_to_bidiagonal (LAPACK dgbbrd; reference kernels.py:43-65) is not used by "
-                              "alg_wrappers and has no HIP implementation yet")
+    """(diag_out, offdiag_out) of the bidiagonal form of the band matrix packed from the blocks `x` (reference
+    kernels.py:43-65).  As written there, block i is placed at rows and columns [i s, (i + 1) s) of a band matrix with
+    kl = ku = s - 1 (s = x[0].shape[0]; every block has to be s x s, otherwise the reference's packing loop raises) --
+    a block-diagonal matrix -- and LAPACK DGBBRD(vect='N') returns d (length s * len(x)) and e (one shorter).  Every block
+    is reduced on its own on the GPU (npw_dgebd2); the entries of e between two blocks are exactly zero.  The
+    bidiagonal form is unique up to the signs of its entries: magnitudes equal DGBBRD's, signs follow DLARFG.
+    ndarray blocks -> ndarrays; DeviceTile blocks -> device vectors."""
+    be = get_backend()
+    stream = _ctx()[0]
+    blocks = list(x)
+    if not blocks:
+        raise IndexError("list index out of range")          # x[0] in the reference
+    s = blocks[0].shape[0]
+    host = any(_is_host(b) for b in blocks)
+    ds, es = [], []
+    for b in blocks:
+        if tuple(b.shape) != (s, s):
+            # the reference's packing `packed_x[a:a + s, col] = block[:, j]` cannot broadcast anything else
+            raise ValueError(f"could not broadcast input array from shape {tuple(b.shape)} into shape ({s},)")
+        t = be.to_device(np.asarray(b, dtype=np.float64), stream) if _is_host(b) else b
+        d, e = be.gebd2(t, stream)
+        ds.append(d)
+        es.append(e)
+    if host:
+        n = s * len(blocks)
+        d_out, e_out = np.zeros(n), np.zeros(max(n - 1, 0))
+        for i, (d, e) in enumerate(zip(ds, es)):
+            d_out[i * s:(i + 1) * s] = be.to_host(d, stream)
+            if s > 1:
+                e_out[i * s:(i + 1) * s - 1] = be.to_host(e, stream)
+        return d_out, e_out
+    zero = be.zeros((1,), np.float64, stream)
+    parts_e = []
+    for i, e in enumerate(es):
+        if s > 1:
+            parts_e.append(e.reshaped((s - 1, 1)))
+        if i + 1 < len(es):
+            parts_e.append(zero.reshaped((1, 1)))
+    d_all = be.vstack([d.reshaped((s, 1)) for d in ds], stream)
+    e_all = be.vstack(parts_e, stream) if parts_e else be.zeros((0, 1), np.float64, stream)
+    return d_all.reshaped((d_all.shape[0],)), e_all.reshaped((e_all.shape[0],))
 
 
 def trsm_sub(L, S, x):

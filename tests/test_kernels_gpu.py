@@ -431,3 +431,29 @@ def test_block_copy_and_reshard_down(hbm_store):
     shard_matrix(X, Xh)
     Y = matrix_init.reshard_down(X, [4, 2])
     assert tuple(Y.shard_sizes) == (32, 32) and np.array_equal(Y.numpy(), Xh)
+
+
+@pytest.mark.parametrize("s,nblk", [(1, 2), (5, 1), (8, 3), (33, 2), (130, 2), (256, 1)])
+def test_banded_to_bidiagonal_vs_oracle(s, nblk):
+    """kernels.banded_to_bidiagonal (reference kernels.py:43-65) against the oracle's restatement: same (d, e) -- both
+    follow DLARFG's signs -- and the singular values of the blocks (the invariant DGBBRD's own output would share)."""
+    rng = np.random.default_rng(s * 10 + nblk)
+    x = [rng.standard_normal((s, s)) for _ in range(nblk)]
+    keep = [b.copy() for b in x]
+    d, e = kernels.banded_to_bidiagonal(x)
+    do, eo = oracle.banded_to_bidiagonal(x)
+    assert d.shape == do.shape and e.shape == eo.shape
+    tol = 1e-12 * s * max(1.0, np.abs(do).max())
+    np.testing.assert_allclose(d, do, rtol=0, atol=tol)
+    np.testing.assert_allclose(e, eo, rtol=0, atol=tol)
+    B = np.diag(d) + np.diag(e, 1)
+    ref = np.sort(np.concatenate([np.linalg.svd(b, compute_uv=False) for b in x]))
+    np.testing.assert_allclose(np.sort(np.linalg.svd(B, compute_uv=False)), ref, atol=1e-12 * s * ref.max())
+    for a, k in zip(x, keep):
+        assert np.array_equal(a, k)
+    # device tiles in, device vectors out
+    be = kernels.get_backend()
+    dd, ee = kernels.banded_to_bidiagonal([be.to_device(b) for b in x])
+    assert np.array_equal(be.to_host(dd), d) and np.array_equal(be.to_host(ee), e)
+    with pytest.raises(ValueError):
+        kernels.banded_to_bidiagonal([x[0], np.zeros((s + 1, s))])

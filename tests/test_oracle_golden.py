@@ -216,3 +216,24 @@ def test_qr_program_golden(tag, b):
     # what the reference's algorithm does get right: the first diagonal block (up to row signs)
     R = np.linalg.qr(X)[1]
     np.testing.assert_allclose(np.abs(Rs.get((0, 0, 0))), np.abs(R[:b, :b]), atol=1e-10)
+
+
+def test_banded_to_bidiagonal_restatement_properties():
+    """kernels.py:43-65 is PARITY-UNPINNED by the reference (its dgbbrd f2py module is fetched from S3, SciPy has no
+    DGBBRD, no reference test calls it): the restatement is pinned through what any B = Q^T A P must satisfy -- the
+    singular values of the band matrix the reference packs (a block-diagonal one) -- and through the packing itself."""
+    rng = np.random.default_rng(12)
+    for s, nblk in [(1, 3), (4, 1), (6, 3), (16, 2)]:
+        x = [rng.standard_normal((s, s)) for _ in range(nblk)]
+        d, e = oracle.banded_to_bidiagonal(x)
+        n = s * nblk
+        assert d.shape == (n,) and e.shape == (n - 1,)
+        B = np.diag(d) + np.diag(e, 1)
+        ref = np.sort(np.concatenate([np.linalg.svd(b, compute_uv=False) for b in x]))
+        np.testing.assert_allclose(np.sort(np.linalg.svd(B, compute_uv=False)), ref, atol=1e-13 * max(1.0, ref.max()))
+        # the entries of e that would couple two blocks are exactly zero (the packed matrix is block diagonal)
+        for i in range(1, nblk):
+            assert e[i * s - 1] == 0.0
+    # a block of another shape cannot be packed (the reference's slice assignment raises the same way)
+    with pytest.raises(ValueError):
+        oracle.banded_to_bidiagonal([rng.standard_normal((4, 4)), rng.standard_normal((3, 4))])
