@@ -121,7 +121,7 @@ def main():
         flops = 2 * m * b * b - 2 * b ** 3 / 3
         print(json.dumps({"what": f"{m} x {b} fp64 TSQR (alg_wrappers.tsqr), {a.leaves} leaves, {2 * a.leaves - 1} tasks",
                           "ms": round(dt * 1e3, 2), "TFLOP/s(2mn^2-2n^3/3)": round(flops / dt / 1e12, 3),
-                          "rel_err_RtR": float(err), "streams": a.streams, "batch_tasks": a.batch or 16}))
+                          "rel_err_RtR": float(err), "streams": a.streams, "batch_tasks": a.batch or 32}))
     elif a.what in ("bdfac", "qr"):
         nt = a.tiles
         n = nt * b
@@ -133,7 +133,7 @@ def main():
         dt, meta = timed(build, a.steps, a.warmup)
         ntasks = len(build()[0].program.tasks)
         out = {"what": f"{n}^2 fp64 alg_wrappers.{a.what}, {b}^2 tiles ({nt} x {nt}), {ntasks} tasks", "ms": round(dt * 1e3, 2),
-               "batch_tasks": a.batch or 16, "streams": a.streams}
+               "batch_tasks": a.batch or 32, "streams": a.streams}
         if a.what == "qr":
             # Rs[0, 0, 0] is the R factor of the first block column's TSQR: R^T R = X0^T X0
             Rs = meta["outputs"][0]
