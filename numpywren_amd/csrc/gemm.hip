@@ -165,6 +165,8 @@ __device__ inline void block_to_tile_tri(int tiles, bool spread, int& tm, int& t
 // trsm / potrf / geqrt run through the same tiling; TAG 2 = its symmetric form (X == Y, lower tiles only).
 template <typename T, int BM, int BN, int BK, bool A_KC, bool B_KC, bool EDGE, int TAG = 0>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) {
+    constexpr int NT = 256;              // threads per workgroup: 4 waves as 2 x 2
+    constexpr int WAVES_N = 2;
     GemmParams<T> p = p_in;
     if (gridDim.z > 1) {
         int64_t bz = blockIdx.z, b2 = 0;
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
     using acc_t = typename TR::acc_t;
     using vec_t = typename TR::vec_t;
     constexpr int VEC = TR::VEC;
-    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int WM = BM / 2, WN = BN / WAVES_N;
     constexpr int TM = WM / 16, TN = WN / 16;
     constexpr int KSTEPS = BK / 4;
     constexpr int LDKC = BK + TR::PADK;
@@ -190,9 +192,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
     constexpr int LDA_MC = BM + TR::PAD_MC, LDB_MC = BN + TR::PAD_MC;
     constexpr int A_ELEMS = A_KC ? BM * LDKC : BK * LDA_MC;
     constexpr int B_ELEMS = B_KC ? BN * LDKC : BK * LDB_MC;
-    constexpr int A_CHUNKS = BM * BK / VEC / 256;
-    constexpr int B_CHUNKS = BN * BK / VEC / 256;
-    static_assert(A_CHUNKS >= 1 && B_CHUNKS >= 1, "tile too small for 256 threads");
+    constexpr int A_CHUNKS = BM * BK / VEC / NT;
+    constexpr int B_CHUNKS = BN * BK / VEC / NT;
+    static_assert(A_CHUNKS >= 1 && B_CHUNKS >= 1, "tile too small for the workgroup");
     static_assert(BK % 8 == 0 && KSTEPS % VEC == 0, "BK");
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
     const int li = lane & 15, lg = lane >> 4;
 
     // split-K: blockIdx.y selects the k range [kb, kend) and its own partial output
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
         const int k0 = kb + kt * BK;
 #pragma unroll
         for (int c = 0; c < A_CHUNKS; ++c) {
-            const int id = tid + 256 * c;
+            const int id = tid + NT * c;
             if constexpr (A_KC) {  // A stored M x K
                 const int row = id / (BK / VEC), kc = (id % (BK / VEC)) * VEC;
                 const T* src = p.A + (int64_t)(m0 + row) * p.lda + (k0 + kc);
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
         }
 #pragma unroll
         for (int c = 0; c < B_CHUNKS; ++c) {
-            const int id = tid + 256 * c;
+            const int id = tid + NT * c;
             if constexpr (B_KC) {  // B stored N x K
                 const int row = id / (BK / VEC), kc = (id % (BK / VEC)) * VEC;
                 const T* src = p.B + (int64_t)(n0 + row) * p.ldb + (k0 + kc);
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int c = 0; c < A_CHUNKS; ++c) {
-            const int id = tid + 256 * c;
+            const int id = tid + NT * c;
             if constexpr (A_KC) {
                 const int row = id / (BK / VEC), kc = (id % (BK / VEC)) * VEC;
                 *reinterpret_cast<vec_t*>(&smem[buf * STAGE + kc_off<T, BK>(row, kc)]) = ra[c];
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
         }
 #pragma unroll
         for (int c = 0; c < B_CHUNKS; ++c) {
-            const int id = tid + 256 * c;
+            const int id = tid + NT * c;
             if constexpr (B_KC) {
                 const int row = id / (BK / VEC), kc = (id % (BK / VEC)) * VEC;
                 *reinterpret_cast<vec_t*>(&smem[buf * STAGE + A_ELEMS + kc_off<T, BK>(row, kc)]) = rb[c];
@@ -363,12 +365,51 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
         load_tiles(0);
         store_tiles(0);
         __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < nk) load_tiles(kt + 1);
-            compute(cur);
-            if (kt + 1 < nk) store_tiles(cur ^ 1);
+        if constexpr (A_KC && B_KC && BM == 128 && BN == 128) {
+            // The LDS stores of the next k-tile are spread between the MFMAs of the LAST step group instead of leaving
+            // as a burst in front of the barrier.  Measured on the 4096^3 trailing update (tools/syrk_time.py): the
+            // loop without the stores runs at 74.7 TFLOP/s -- the bare-MFMA ceiling; the barrier costs nothing -- with
+            // the burst at 68.5, because 32 back-to-back ds_write_b128 per workgroup keep the LDS busy for ~400 cycles
+            // during which the OTHER workgroup's fragment reads (and with them its MFMAs) wait, and the storing
+            // workgroup sits at its barrier and cannot fill in.  One store per few MFMAs hides in the matrix pipe's
+            // 64-cycle shadow: 67.3 -> 69.0 TFLOP/s.  (Direct-to-LDS loads, global_load_lds_dwordx4, were tried
+            // instead of the register staging: +1.4 % only -- the LDS array is the contended resource, not the VGPR
+            // path -- and 8 waves per workgroup changed nothing: latency hiding is not what is missing.)
+            // The last iteration is peeled so that loads, MFMAs and stores of the others share one basic block, and
+            // the issue order is pinned with sched_group_barrier (0x100 = LDS read, 0x008 = MFMA, 0x200 = LDS write).
+            // (Only for the 128 x 128 tiling -- long k loops, two workgroups per CU.  The small tilings run grids of
+            //  well under two workgroups per CU where pinning the order costs more than the burst: trsm 1.29 -> 1.51 ms.)
+            constexpr int GROUPS = KSTEPS / VEC;               // fragment loads per k-tile (VEC MFMA steps each)
+            constexpr int MF = VEC * TM * TN;                  // MFMAs per group
+            constexpr int NST = A_CHUNKS + B_CHUNKS;           // 16-byte LDS stores per thread and k-tile
+            constexpr int HALF = GROUPS * MF / 2;              // the stores go between the MFMAs of the second half
+            constexpr int PER = HALF / NST;
+            static_assert(PER >= 1 && GROUPS <= 2, "store interleave: unexpected tile geometry");
+            for (int kt = 0; kt + 1 < nk; ++kt) {
+                const int cur = kt & 1;
+                load_tiles(kt + 1);
+                compute(cur);
+                store_tiles(cur ^ 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);       // fragments of the first group
+                __builtin_amdgcn_sched_group_barrier(0x008, HALF, 0);          // first half of the MFMAs
+                if constexpr (GROUPS == 2) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+                for (int g = 0; g < NST; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+                __syncthreads();
+            }
+            compute((nk - 1) & 1);
             __syncthreads();
+        } else {
+            for (int kt = 0; kt < nk; ++kt) {
+                const int cur = kt & 1;
+                if (kt + 1 < nk) load_tiles(kt + 1);
+                compute(cur);
+                if (kt + 1 < nk) store_tiles(cur ^ 1);
+                __syncthreads();
+            }
         }
     }
 
