@@ -33,8 +33,8 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense fp64 matrix peak (vendor spec; 74.6 measured by tools/devcheck)
 TILE = 4096
-SYRK_TRAFFIC_BYTES = 2.98e9    # PMC passes of a separate run (2 x FETCH_SIZE + WRITE_SIZE per launch of the tagged kernel)
-SYRK_TRAFFIC_SOURCE = "profiles/r02_bench_pmc_traffic.json (rocprofv3 --pmc, separate passes)"
+SYRK_TRAFFIC_BYTES = 2.65e9    # PMC passes of a separate run (2 x FETCH_SIZE + WRITE_SIZE per launch of the tagged kernel)
+SYRK_TRAFFIC_SOURCE = "profiles/r02_bench_pmc.json (rocprofv3 --pmc, separate passes)"
 
 
 def build_input(be, nb, b, key, rank=0, world=1, owner=None):
