@@ -414,8 +414,8 @@ def _qr_factor_triangular(be, stream, x0, x1, **kwargs):
          of x1 and does not touch the part below, so this is tril(x1, -1) + I: the identity for the triangular inputs of
          the QR tree.  (The reference's alg_wrappers.qr therefore only gets the first block row of R right; we reproduce
          it as written -- see tests/golden/make_golden_qr.py and DESIGN.md section 7.)
-    Dense formulation: the Householder vectors of the stacked matrix keep DTPQRT's sparsity, so one npw_dgeqrt of the
-    2n x n stack gives the same R and the same per-panel T blocks to rounding."""
+    On the GPU: npw_dtpqrt_batched (the structured factorisation of two stacked triangles) gives R and the full n x n T,
+    whose nb x nb diagonal blocks are DTPQRT's blocked T (npw_dblockdiag_rows lays them side by side)."""
     n = x0.shape[-1]
     if tuple(x0.shape) != (n, n) or tuple(x1.shape) != (n, n):
         raise NotImplementedError(f"qr_factor_triangular of {x0.shape} over {x1.shape}: only square tiles of equal size "
