@@ -137,7 +137,7 @@ def test_chol_not_positive_definite():
         kernels.chol(A)
 
 
-@pytest.mark.parametrize("n", [129, 192, 257, 300, 511, 513, 640, 1000])
+@pytest.mark.parametrize("n", [129, 192, 256, 257, 300, 384, 511, 513, 640, 1000, 1536])
 def test_chol_block_column_handoff(n):
     """Sizes with at least one fused block-column launch (diagonal block + panel rows that follow it one 16-column
     step behind through tagged-slot messages): odd leading dimensions (scalar write-through stores), a single panel
@@ -157,7 +157,7 @@ def test_chol_block_column_handoff(n):
     assert np.array_equal(kernels.chol(a), L)
 
 
-@pytest.mark.parametrize("n,bad", [(300, 5), (300, 140), (300, 299), (640, 128), (640, 400), (1000, 600)])
+@pytest.mark.parametrize("n,bad", [(300, 5), (300, 140), (300, 299), (256, 3), (256, 200), (640, 128), (640, 400), (1000, 600), (1024, 1023)])
 def test_chol_failure_is_reported_from_any_block_column(n, bad):
     """A non-positive pivot in any block column: LinAlgError, and the panel workgroups that were waiting for the
     rest of that block column's messages are released (the call returns instead of spinning)."""

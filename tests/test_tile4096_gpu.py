@@ -257,3 +257,40 @@ def test_config4_gemm32_8192(hbm_store):
             assert got.dtype == np.float64          # reference quirk a5: add_matrices promotes
             np.testing.assert_allclose(got[rows], ref[:, j * B:(j + 1) * B], rtol=1e-3, atol=1e-2 * np.sqrt(n))
     program.free()
+
+
+@pytest.mark.parametrize("dtype,m,n,k", [(np.float64, 1801, 1795, 1003), (np.float32, 2048, 2048, 2048), (np.float32, 1801, 1795, 1003)])
+def test_big_tile_nt_paths(dtype, m, n, k):
+    """The 128 x 128 KC/KC instantiations with the pinned store / MFMA interleave that nothing else reaches: ragged
+    shapes (EDGE variant: >= 192 tiles of 128 x 128) and fp32 (one fragment group per k-tile) -- op(A) = N, op(B) = T."""
+    be = get_backend()
+    rng = np.random.default_rng(m + k)
+    A = rng.standard_normal((m, k)).astype(dtype)
+    Bm = rng.standard_normal((n, k)).astype(dtype)
+    got = be.to_host(be.gemm(be.to_device(A), be.to_device(Bm), False, True))
+    ref = A.astype(np.float64) @ Bm.astype(np.float64).T
+    if dtype == np.float64:
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-13 * k * 4)
+    else:
+        assert got.dtype == np.float32
+        np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-2 * np.sqrt(k))
+
+
+def test_chol_8192_lookahead_limits():
+    """The largest tile the look-ahead factorisation takes (64 block columns, 127 chain workgroups, two strips per
+    workgroup in the first launches): residual and triangular structure on the device, and the factor's cached block
+    inverses through a trsm."""
+    be = get_backend()
+    n = 8192
+    G = be.fill_random((n, 192), seed=21)
+    A = be.add_diag(be.gemm(G, G, False, True), float(n))
+    L, info = be.chol(A)
+    assert be.read_flag(info) == 0
+    R = be.gemm(L, L, False, True, alpha=-1.0, beta=1.0, C=A)
+    assert np.sqrt(be.sumsq(R) / be.sumsq(A)) < 1e-14
+    U = be.tri(L, "U")                    # upper triangle incl. diagonal: only the diagonal may be non-zero
+    assert be.sumsq(U) > 0 and not np.triu(be.to_host(be.block(L, 0, 512, 0, 512)), 1).any()
+    Y = be.fill_random((256, n), seed=22)
+    X = be.trsm(L, Y)
+    Rt = be.gemm(X, L, False, True, alpha=1.0, beta=-1.0, C=Y)
+    assert np.sqrt(be.sumsq(Rt) / be.sumsq(Y)) < 1e-13
