@@ -74,3 +74,28 @@ def test_bench_distributed_path_on_one_gpu():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["config"]["transport"] == "rccl" and line["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,extra,port", [("chol", ["--tiles", "4"], 29671), ("tsqr", ["--leaves", "8"], 29672),
+                                                 ("gemm32", ["--tiles", "2"], 29673)])
+def test_bench_two_ranks_on_one_gpu(workload, extra, port):
+    """bench.py's N > 1 path end to end -- torchrun, ownership, owner-only input generation, the distributed executor,
+    barrier + max-over-ranks timing, rank 0's single JSON line -- with two ranks sharing this box's one GPU (payloads
+    staged through the host: RCCL refuses two ranks on a device; the RCCL transport itself is covered by
+    tests/test_comm_gpu.py)."""
+    env = dict(os.environ, NUMPYWREN_AMD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("NUMPYWREN_AMD_STORE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--tile", "256",
+           "--workload", workload] + extra
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    for k, t in REQUIRED.items():
+        assert k in line and isinstance(line[k], t), k
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["transport"] == "host"
+    if workload == "chol":
+        assert line["scaling"] == "strong" and line["config"]["bytes_sent_rank0"] > 0
