@@ -158,6 +158,13 @@ size_t npw_dtrsm_rltn_inv_workspace_bytes(int64_t m, int64_t n);
 int npw_dtrsm_rltn_inv(int64_t m, int64_t n, const double* L, int64_t ldl, const double* Winv,
                        const double* B, int64_t ldb, double* X, int64_t ldx, void* workspace,
                        npw_stream_t stream);
+/* The same solve for `count` (<= 16) right-hand sides that share L -- the trsm tasks of one block column of the Cholesky
+ * DAG (reference algs.py:236-249, statements 1 and 4: O[j, i] = trsm(O[i, i], S[i, j, i]) for every j > i) -- as ONE
+ * sequence of batched launches: B[z], X[z] are m x n tiles in separate allocations (16-byte aligned, never aliased);
+ * workspace: count * npw_dtrsm_rltn_inv_workspace_bytes(m, n).  Same numbers as count separate calls.             */
+int npw_dtrsm_rltn_inv_batched(int count, int64_t m, int64_t n, const double* L, int64_t ldl, const double* Winv,
+                               const double* const* B, int64_t ldb, double* const* X, int64_t ldx, void* workspace,
+                               npw_stream_t stream);
 
 /* Cholesky factor of the n x n SPD matrix A (only its lower triangle is read):
  * Lout = lower triangular L with A = L L^T, strictly-upper part of Lout set to 0.

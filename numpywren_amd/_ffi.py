@@ -70,6 +70,7 @@ PROTOTYPES = {
     "npw_dtrtri_diag": (c_int, [_i64, _vp, _i64, _vp, _vp]),
     "npw_dtrsm_rltn_inv_workspace_bytes": (_sz, [_i64, _i64]),
     "npw_dtrsm_rltn_inv": (c_int, [_i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "npw_dtrsm_rltn_inv_batched": (c_int, [c_int, _i64, _i64, _vp, _i64, _vp, POINTER(_vp), _i64, POINTER(_vp), _i64, _vp, _vp]),
     "npw_dpotrf_lower_workspace_bytes": (_sz, [_i64]),
     "npw_dpotrf_lower": (c_int, [_i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "npw_dgeqrt_workspace_bytes": (_sz, [_i64, _i64]),

@@ -1236,7 +1236,26 @@ struct TrsmCtx {
     int64_t c0;  // absolute column offset of X's / B's / T's column 0 inside L (potrf panels)
     hipStream_t s;
     bool groups_ready = false;  // Winv's full LW groups are complete inverses (complete_groups ran)
+    // several right-hand sides that share L (the trsm tasks of one block column of the Cholesky DAG) as ONE solve: every
+    // GEMM of the recursion runs as a batch with blockIdx.z = right-hand side; B, X, T above are those of problem 0 and
+    // problem z's are dB[z], dX[z], dT[z] elements further (separate allocations: no constant stride)
+    int count = 1;
+    const int64_t* dB = nullptr;
+    const int64_t* dX = nullptr;
+    const int64_t* dT = nullptr;
 };
+
+// batch options of one GEMM of the recursion: which of B / X / T each operand walks over (L and Winv are shared)
+inline GemmOpts trsm_batch(const TrsmCtx& c, const int64_t* da, const int64_t* dc, const int64_t* dd) {
+    GemmOpts o;
+    if (c.count > 1) {
+        o.batch = c.count;
+        o.delta_a = da;
+        o.delta_c = dc;
+        o.delta_d = dd;
+    }
+    return o;
+}
 
 // solve the column range [coff, coff + n) (relative to the panel); `touched`: its current values are in T
 int trsm_rec(const TrsmCtx& c, int64_t coff, int64_t n, bool touched) {
@@ -1245,13 +1264,13 @@ int trsm_rec(const TrsmCtx& c, int64_t coff, int64_t n, bool touched) {
     if (n <= NB || group_leaf) {
         const double* Wb = group_leaf ? c.Winv + (size_t)(col / LW) * LW * LW : c.Winv + w_block_offset(col / NB);
         double* Xj = c.X + coff;
-        GemmOpts o;
+        GemmOpts o = trsm_batch(c, touched ? c.dT : c.dB, nullptr, c.dX);
         o.b_lower_tri = group_leaf;  // inv(L_group) is lower triangular: column tile n0 stops at k = n0 + BN
         if (touched)
             return gemm<double>('N', 'T', c.m, n, n, 1.0, c.T + coff, c.ldt, Wb, LW, 0.0, nullptr, 0, Xj, c.ldx, o, c.s);
         if ((const void*)c.B != (const void*)c.X)
             return gemm<double>('N', 'T', c.m, n, n, 1.0, c.B + coff, c.ldb, Wb, LW, 0.0, nullptr, 0, Xj, c.ldx, o, c.s);
-        NPW_REQUIRE(!group_leaf, "trsm: in-place panels use NB-wide leaves");
+        NPW_REQUIRE(!group_leaf && c.count == 1, "trsm: in-place panels use NB-wide leaves and are not batched");
         o.inplace_a = true;  // in-place solve of the first block of an in-place panel (row-panel tiling)
         return gemm<double>('N', 'T', c.m, n, n, 1.0, Xj, c.ldx, Wb, LW, 0.0, nullptr, 0, Xj, c.ldx, o, c.s);
     }
@@ -1263,7 +1282,7 @@ int trsm_rec(const TrsmCtx& c, int64_t coff, int64_t n, bool touched) {
     const double* C2 = touched ? c.T + coff + n1 : c.B + coff + n1;
     const int64_t ldc = touched ? c.ldt : c.ldb;
     rc = gemm<double>('N', 'T', c.m, n2, n1, -1.0, c.X + coff, c.ldx, L21, c.ldl, 1.0, C2, ldc, c.T + coff + n1, c.ldt,
-                      GemmOpts(), c.s);
+                      trsm_batch(c, c.dX, touched ? c.dT : c.dB, c.dT), c.s);
     if (rc) return rc;
     return trsm_rec(c, coff + n1, n2, true);
 }
@@ -1426,6 +1445,33 @@ int npw_dtrsm_rltn_inv(int64_t m, int64_t n, const double* L, int64_t ldl, const
     }
     TrsmCtx c{m, L, ldl, B, ldb, X, ldx, static_cast<double*>(workspace), n, Winv, 0, as_stream(stream)};
     c.groups_ready = true;  // Winv comes from npw_dtrtri_diag or npw_dpotrf_lower, which both complete the groups
+    return trsm_rec(c, 0, n, false);
+}
+
+int npw_dtrsm_rltn_inv_batched(int count, int64_t m, int64_t n, const double* L, int64_t ldl, const double* Winv,
+                               const double* const* B, int64_t ldb, double* const* X, int64_t ldx, void* workspace,
+                               npw_stream_t stream) {
+    NPW_REQUIRE(count >= 0 && m >= 0 && n >= 0, "npw_dtrsm_rltn_inv_batched: negative argument");
+    if (count == 0 || m == 0 || n == 0) return NPW_OK;
+    NPW_REQUIRE(count <= 16, "npw_dtrsm_rltn_inv_batched: at most 16 right-hand sides per call");
+    NPW_REQUIRE(L && Winv && B && X && workspace, "npw_dtrsm_rltn_inv_batched: NULL argument");
+    NPW_REQUIRE(ldl >= n && ldb >= n && ldx >= n, "npw_dtrsm_rltn_inv_batched: leading dimension too small");
+    NPW_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "npw_dtrsm_rltn_inv_batched: workspace not 16B aligned");
+    int64_t dB[16], dX[16], dT[16];
+    for (int z = 0; z < count; ++z) {
+        NPW_REQUIRE(B[z] && X[z] && (const void*)B[z] != (const void*)X[z], "npw_dtrsm_rltn_inv_batched: B[%d] / X[%d] NULL or aliased", z, z);
+        NPW_REQUIRE(((reinterpret_cast<uintptr_t>(B[z]) | reinterpret_cast<uintptr_t>(X[z])) & 15) == 0,
+                    "npw_dtrsm_rltn_inv_batched: tiles must be 16-byte aligned");
+        dB[z] = B[z] - B[0];
+        dX[z] = X[z] - X[0];
+        dT[z] = (int64_t)z * m * n;
+    }
+    TrsmCtx c{m, L, ldl, B[0], ldb, X[0], ldx, static_cast<double*>(workspace), n, Winv, 0, as_stream(stream)};
+    c.groups_ready = true;
+    c.count = count;
+    c.dB = dB;
+    c.dX = dX;
+    c.dT = dT;
     return trsm_rec(c, 0, n, false);
 }
 

@@ -113,6 +113,8 @@ struct GemmParams {
     int b_lower_tri;                                  // k range of column tile n0 ends at n0 + BN
     int k_from_diag;                                  // k range of tile (m0, n0) starts at max(m0, n0) (trapezoidal operands)
     int a_upper_tri;                                  // k range of row tile m0 starts at m0 (op(A) upper triangular)
+    int use_delta;                                    // irregular batch: element offsets per problem instead of strides
+    int64_t da[16], db[16], dc[16], dd[16];
 };
 
 // XCD-aware + grouped mapping of the linear block id to an output tile.
@@ -168,7 +170,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
     constexpr int NT = 256;              // threads per workgroup: 4 waves as 2 x 2
     constexpr int WAVES_N = 2;
     GemmParams<T> p = p_in;
-    if (gridDim.z > 1) {
+    if (gridDim.z > 1 && p.use_delta) {
+        // (indexed in the kernel-argument segment itself: a dynamically indexed array inside the local copy `p` would
+        //  push the whole parameter block out of the scalar registers -- the trailing update lost 8 % that way)
+        const int bz = blockIdx.z;
+        p.A += p_in.da[bz];
+        p.B += p_in.db[bz];
+        if (p.C) p.C += p_in.dc[bz];
+        p.D += p_in.dd[bz];
+    } else if (gridDim.z > 1) {
         int64_t bz = blockIdx.z, b2 = 0;
         if (p.batch_inner > 0) {
             b2 = bz % p.batch_inner;
@@ -693,6 +703,22 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
     p.b_lower_tri = opts.b_lower_tri ? 1 : 0;
     p.k_from_diag = opts.k_from_diag ? 1 : 0;
     p.a_upper_tri = opts.a_upper_tri ? 1 : 0;
+    p.use_delta = 0;
+    if (opts.delta_a || opts.delta_b || opts.delta_c || opts.delta_d) {
+        NPW_REQUIRE(opts.batch <= 16 && opts.batch_inner == 0, "gemm: an irregular batch holds at most 16 problems");
+        for (int z = 0; z < opts.batch; ++z)   // the vectorised tilings need every problem's rows 16-byte aligned
+            NPW_REQUIRE((!opts.delta_a || opts.delta_a[z] % (16 / (int)sizeof(T)) == 0) &&
+                            (!opts.delta_b || opts.delta_b[z] % (16 / (int)sizeof(T)) == 0),
+                        "gemm: irregular batch offsets must keep 16-byte alignment");
+        p.use_delta = 1;
+        for (int z = 0; z < 16; ++z) {
+            const bool in = z < opts.batch;
+            p.da[z] = (in && opts.delta_a) ? opts.delta_a[z] : (in ? (int64_t)z * opts.batch_a : 0);
+            p.db[z] = (in && opts.delta_b) ? opts.delta_b[z] : (in ? (int64_t)z * opts.batch_b : 0);
+            p.dc[z] = (in && opts.delta_c) ? opts.delta_c[z] : (in ? (int64_t)z * opts.batch_c : 0);
+            p.dd[z] = (in && opts.delta_d) ? opts.delta_d[z] : (in ? (int64_t)z * opts.batch_d : 0);
+        }
+    }
     p.tag = opts.tag;
     p.k_chunk = opts.k_chunk_;
     p.split_stride = opts.k_chunk_ > 0 ? m * n : 0;
@@ -721,6 +747,8 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
     }
     // tile selection: 128x128 when it fills the chip (or the problem is large), else 64x64
     const int64_t t128 = ceil_div(m, 128);
+    // (per problem, also for batches: counting the batch in moved trsm's batched 512-wide leaves to 128 x 128 tiles, whose
+    //  coarser k-limits cost more than the fuller grid gains: 1.21 -> 1.41 ms per right-hand side)
     const int64_t wg128 = (p.lower_only >= 2) ? t128 * (t128 + 1) / 2 : t128 * ceil_div(n, 128);
     static const int64_t big_min = [] {
         const char* e = getenv("NPW_GEMM_BIG_MIN");

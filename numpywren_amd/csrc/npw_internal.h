@@ -65,6 +65,12 @@ struct GemmOpts {
     bool b_lower_tri = false;  // op(B) = W^T with W (n x k) lower triangular: column tile n0 only needs k < n0 + BN
     bool k_from_diag = false;  // op(A)^T, op(B) (k x m, k x n) lower trapezoidal: tile (m0, n0) only needs k >= max(m0, n0)
     bool a_upper_tri = false;  // op(A) (m x k) upper triangular: row tile m0 only needs k >= m0
+    // Irregular batch: problem z's operand is (pointer of problem 0) + delta_x[z] ELEMENTS instead of z * batch_x
+    // (tiles of one batch live in separate allocations).  Arrays of `batch` entries (<= 16) or NULL.
+    const int64_t* delta_a = nullptr;
+    const int64_t* delta_b = nullptr;
+    const int64_t* delta_c = nullptr;
+    const int64_t* delta_d = nullptr;
 };
 
 // D = alpha * op(A) op(B) + beta * C

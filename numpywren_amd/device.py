@@ -800,6 +800,52 @@ class HipBackend(object):
         self._produced(sh, out)
         return out
 
+    def trsm_batched(self, L, Ys, stream=None, exact_zero=True):
+        """[Y L^-T for Y in Ys] for right-hand sides that share the factor L (the trsm tasks of one block column of the
+        Cholesky DAG) as ONE sequence of batched launches (npw_dtrsm_rltn_inv_batched): the GEMMs of the recursive
+        solve get len(Ys) times the rows and fill the chip where a single tile's do not.  Same numbers as `trsm`."""
+        sh = self._sh(stream)
+        L = self.as_f64(L, sh)
+        Ys = [self.as_f64(y, sh) for y in Ys]
+        n = L.shape[0]
+        m = Ys[0].shape[0]
+        if len(Ys) == 1 or len(Ys) > 16 or L.shape[1] != n or any(y.shape != (m, n) for y in Ys):
+            return [self.trsm(L, y, stream, exact_zero) for y in Ys]
+        count = len(Ys)
+        tb = m * n * 8
+        Xbuf = self.alloc(count * tb)
+        Xbuf.streams.add(sh)
+        outs = [DeviceTile(Xbuf, (m, n), _F64, z * tb) for z in range(count)]
+        self._use(sh, L, *Ys)
+        aux = L.buf.aux if L.buf.aux is not None else {}
+        cached = aux.get("diag_inv") if L.offset == 0 else None
+        if cached is None:
+            winv = self.alloc(max(16, self.lib.npw_dtrtri_diag_bytes(n)))
+            winv.streams.add(sh)
+            _ffi.check(self.lib.npw_dtrtri_diag(n, L.ptr, n, winv.ptr, sh), "trtri_diag")
+            cached = (winv, (self.record_new(sh), sh))
+            if L.offset == 0:
+                aux["diag_inv"] = cached
+                L.buf.aux = aux
+        winv, ready = cached
+        if ready is not None and ready[1] != sh:
+            self.wait_event(sh, ready[0])
+        winv.streams.add(sh)
+        ws = self.alloc(max(16, count * self.lib.npw_dtrsm_rltn_inv_workspace_bytes(m, n)))
+        ws.streams.add(sh)
+        pb = (ctypes.c_void_p * count)(*[y.ptr for y in Ys])
+        px = (ctypes.c_void_p * count)(*[x.ptr for x in outs])
+        t0 = self._tic("trsm_batch", sh)
+        _ffi.check(self.lib.npw_dtrsm_rltn_inv_batched(count, m, n, L.ptr, n, winv.ptr, pb, n, px, n, ws.ptr, sh), "trsm_batched")
+        self._toc("trsm_batch", sh, t0)
+        if exact_zero:
+            for y, x in zip(Ys, outs):   # reference: `if np.allclose(y, 0): return np.zeros(...)` -- a device-side select
+                fy = self.zero_flag(y, sh)
+                fy.streams.add(sh)
+                _ffi.check(self.lib.npw_zero_if(x.ptr, m, n, n, fy.ptr, sh), "zero_if")
+        self._produced(sh, *outs)
+        return outs
+
     def chol(self, A, stream=None, info_out=None):
         """Lower Cholesky factor (kernels.chol).  Returns (L, info_buffer); info is a device int32."""
         self._require_2d(A, "chol")

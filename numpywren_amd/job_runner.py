@@ -345,6 +345,28 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
                 break
             e, v = node
             t0 = time.time()
+            if ex.batch_fn(e) is not None and getattr(ex.compiled.kernel(e), "_npw_batch_gather", False):
+                # A batched kind whose siblings become ready one at a time (the trsm tasks of a block column wait for
+                # their trailing updates): first issue the ready tasks that are the last missing parent of a sibling,
+                # then come back to this task -- by then its siblings are in the heap and join the batch.
+                enablers = program.dequeue_enablers(e)
+                if enablers:
+                    program._enqueue(node)
+                    for ne, nv in enablers:
+                        program.set_node_status(ne, nv, lp.NS.RUNNING)
+                        try:
+                            last = ex.run_task(ne, nv)
+                        except Exception as exc:
+                            program.handle_exception(exc, tb=traceback.format_exc(), expr_idx=ne, var_values=nv)
+                            raise
+                        program.post_op(ne, nv, lp.PS.SUCCESS, None)
+                        program.set_node_status(ne, nv, lp.NS.FINISHED)
+                        executed.append([ne, nv])
+                        refs.append((ne, nv))
+                        if last is not None and last.ready is not None:
+                            inflight.append(last)
+                    running_times.append((t0, time.time()))
+                    continue
             # independent ready tasks of the same latency-bound kind (TSQR leaves, the nodes of a tree level) go to
             # the device as ONE batched launch sequence
             group = [(e, v)]

@@ -141,6 +141,36 @@ def _trsm(be, stream, x, y, lower=False, right=True, *args, **kwargs):
 trsm = _trsm
 
 
+def _trsm_batch(be, stream, arg_lists, kwargs_list):
+    """Ready trsm tasks of one statement as batched solves: tasks that share their factor tile (one block column of
+    the Cholesky DAG: O[j, i] = trsm(O[i, i], S[i, j, i]) for every j > i, reference algs.py:242, 246) go to the device as
+    ONE solve with stacked right-hand sides (HipBackend.trsm_batched); anything else one by one.  Same outputs as
+    `trsm` for each task."""
+    exact = _ctx()[2]
+    out = [None] * len(arg_lists)
+    groups = {}
+    for pos, (args, kw) in enumerate(zip(arg_lists, kwargs_list)):
+        x, y = args[0], args[1]
+        plain = (len(args) == 2 and not kw and isinstance(x, DeviceTile) and isinstance(y, DeviceTile) and x.ndim == 2 and
+                 y.ndim == 2 and x.shape[0] == x.shape[1] == y.shape[1] and y.shape[0] == x.shape[1])
+        if plain:
+            groups.setdefault((id(x.buf), x.offset, x.shape, y.shape), []).append(pos)
+        else:
+            out[pos] = _trsm(*args, **kw)
+    for key, members in groups.items():
+        L = arg_lists[members[0]][0]
+        for i in range(0, len(members), 16):
+            part = members[i:i + 16]
+            res = be.trsm_batched(L, [arg_lists[p][1] for p in part], stream, exact_zero=exact)
+            for p, r in zip(part, res):
+                out[p] = r
+    return out
+
+
+trsm._npw_batch = _trsm_batch
+trsm._npw_batch_gather = True   # worth reordering for: the executor first runs the ready tasks that enable further siblings
+
+
 def _trsm_flops(x, y):
     # defined by the reference but never attached (kernels.py:259-263): trsm counts 0 flops there
     if len(y.shape) == 0:

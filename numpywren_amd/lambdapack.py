@@ -359,6 +359,33 @@ class LambdaPackProgram(object):
                 heapq.heapify(self._ready)
             return taken
 
+    def dequeue_enablers(self, expr_idx, limit=64):
+        """Ready tasks (removed from the heap, best priority first) whose completion makes a task of statement
+        `expr_idx` ready -- i.e. they are the LAST missing parent of such a task.  The executor runs them before a
+        batched task of that statement so that its siblings join the batch (the trsm tasks of one block column of the
+        Cholesky DAG become ready one by one as their trailing updates are issued).  Any order of ready tasks is a valid
+        schedule; this one only changes which of them goes first."""
+        with self._lock:
+            items = sorted(self._ready)
+            taken, kept = [], []
+            for item in items:
+                e, v = item[2]
+                ok = False
+                if len(taken) < limit and e != expr_idx:
+                    me = self._node_str(e, v)
+                    for child in self.program.find_children(e, v):
+                        if child[0] != expr_idx:
+                            continue
+                        edges = self._edges.get(self._node_str(*child), ())
+                        if me not in edges and len(edges) == len(self.program.find_parents(child[0], child[1])) - 1:
+                            ok = True
+                            break
+                (taken if ok else kept).append(item)
+            if taken:
+                self._ready = kept
+                heapq.heapify(self._ready)
+        return [t[2] for t in taken]
+
     def num_ready(self):
         with self._lock:
             return len(self._ready)

@@ -144,6 +144,10 @@ class OracleBackend(object):
             return HostTile(oracle.syrk(S.array, X.array, Y.array))
         return HostTile(S.array - X.array @ Y.array.T)
 
+    def trsm_batched(self, L, Ys, stream=None, exact_zero=True):
+        self.calls.append(("trsm_batched", len(Ys)))
+        return [self.trsm(L, y, stream, exact_zero) for y in Ys]
+
     def trsm(self, L, Y, stream=None, exact_zero=True):
         self.calls.append(("trsm", stream))
         if exact_zero and np.allclose(Y.array, 0):

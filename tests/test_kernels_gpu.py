@@ -457,3 +457,60 @@ def test_banded_to_bidiagonal_vs_oracle(s, nblk):
     assert np.array_equal(be.to_host(dd), d) and np.array_equal(be.to_host(ee), e)
     with pytest.raises(ValueError):
         kernels.banded_to_bidiagonal([x[0], np.zeros((s + 1, s))])
+
+
+@pytest.mark.parametrize("n,m,count", [(64, 64, 2), (300, 200, 3), (640, 640, 5), (1024, 512, 16), (2048, 2048, 3)])
+def test_trsm_batched_equals_one_by_one(n, m, count):
+    """npw_dtrsm_rltn_inv_batched (right-hand sides in separate allocations sharing one factor -- the trsm tasks of a
+    block column) against `trsm` on each and against the oracle; one all-zero right-hand side takes the reference's
+    short-circuit inside the batch."""
+    be = kernels.get_backend()
+    rng = np.random.default_rng(n + m + count)
+    G = rng.standard_normal((n, n))
+    Lh = np.linalg.cholesky(G @ G.T + n * np.eye(n))
+    Ys = [rng.standard_normal((m, n)) for _ in range(count)]
+    Ys[-1] = np.zeros((m, n))
+    L = be.to_device(Lh)
+    junk = [be.fill_random((7 + i, 5), i) for i in range(3)]     # perturb the allocator: no constant stride between tiles
+    tiles = [be.to_device(y) for y in Ys]
+    got = be.trsm_batched(L, tiles)
+    assert len(got) == count
+    for y, t, x in zip(Ys, tiles, got):
+        one = be.to_host(be.trsm(L, t))
+        xb = be.to_host(x)
+        assert np.array_equal(xb, one) or np.abs(xb - one).max() <= 1e-13 * max(1.0, np.abs(one).max())
+        ref = oracle.trsm(Lh, y) if y.any() else np.zeros((m, n))
+        np.testing.assert_allclose(xb, ref, rtol=1e-9, atol=1e-10)
+    assert not be.to_host(got[-1]).any()
+    del junk
+
+
+def test_trsm_tasks_of_a_block_column_run_as_one_batch(hbm_store):
+    """The executor issues the trailing updates that enable further trsm tasks first and then runs the block column's
+    trsm tasks as ONE batched solve (kernels.trsm._npw_batch); the factor is what the reference's order gives."""
+    from numpywren_amd import alg_wrappers, job_runner
+    from numpywren_amd import lambdapack as lp
+    from numpywren_amd.matrix import BigMatrix
+    from numpywren_amd.matrix_init import shard_matrix
+    be = kernels.get_backend()
+    rng = np.random.default_rng(77)
+    n, b = 1280, 256
+    G = rng.standard_normal((n, 64))
+    A = G @ G.T + n * np.eye(n)
+    X = BigMatrix("trsm_batch_chol", shape=A.shape, shard_sizes=(b, b))
+    shard_matrix(X, A)
+    program, meta = alg_wrappers.cholesky(X)
+    be.enable_kernel_timers(("trsm_batch", "trsm"))
+    program.start()
+    res = job_runner.lambdapack_run(program, timeout=300)
+    program.wait()
+    times = be.collect_kernel_times()
+    assert program.program_status() == lp.PS.SUCCESS, program.exceptions
+    nb = n // b
+    assert len(res["executed_messages"]) == nb * (nb + 1) * (nb + 2) // 6
+    # block columns 0 .. nb-3 have >= 2 trsm tasks each: one batched call per column; the last column's single task alone
+    assert len(times["trsm_batch"]) == nb - 2 and len(times["trsm"]) == 1
+    L = meta["outputs"][0].numpy()
+    ref = oracle.cholesky(A, b)
+    np.testing.assert_allclose(L, ref, rtol=1e-10, atol=1e-10 * np.abs(ref).max())
+    program.free()
