@@ -385,8 +385,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
             // 64-cycle shadow: 67.3 -> 69.0 TFLOP/s.  (Direct-to-LDS loads, global_load_lds_dwordx4, were tried
             // instead of the register staging: +1.4 % only -- the LDS array is the contended resource, not the VGPR
             // path -- and 8 waves per workgroup changed nothing: latency hiding is not what is missing.)
+            // The global loads of the next k-tile get the same treatment in the FIRST half of the MFMAs (0x020 = VMEM
+            // read): 69.9 -> 71.5 TFLOP/s.  Spreading the second group's fragment reads as well gains nothing.
             // The last iteration is peeled so that loads, MFMAs and stores of the others share one basic block, and
-            // the issue order is pinned with sched_group_barrier (0x100 = LDS read, 0x008 = MFMA, 0x200 = LDS write).
+            // the issue order is pinned with sched_group_barrier (0x100 = LDS read, 0x008 = MFMA, 0x200 = LDS write, 0x020 = VMEM read).
             // (Only for the 128 x 128 tiling -- long k loops, two workgroups per CU.  The small tilings run grids of
             //  well under two workgroups per CU where pinning the order costs more than the burst: trsm 1.29 -> 1.51 ms.)
             constexpr int GROUPS = KSTEPS / VEC;               // fragment loads per k-tile (VEC MFMA steps each)
@@ -401,7 +403,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
                 compute(cur);
                 store_tiles(cur ^ 1);
                 __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);       // fragments of the first group
-                __builtin_amdgcn_sched_group_barrier(0x008, HALF, 0);          // first half of the MFMAs
+                // first half of the MFMAs, the global loads of the next k-tile between them (one per PER MFMAs: as a burst
+                // at the top of the iteration they cost 1.5 %; spread, the wave's memory instructions never queue)
+#pragma unroll
+                for (int g = 0; g < NST; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
                 if constexpr (GROUPS == 2) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
 #pragma unroll
                 for (int g = 0; g < NST; ++g) {
