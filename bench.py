@@ -277,6 +277,8 @@ def main():
         comm = dist.init_process_group()   # control: gloo; payload: RCCL over xGMI (npw_comm_*), one process per GPU
     be = get_backend()
     b = args.tile
+    from numpywren_amd import config as npw_config
+    chain_cus = int(npw_config.default()["executor"].get("chain_cus", 0) or 0) if (world == 1 and args.streams == 1) else 0
     run = Runner(be, comm, args.streams, args.priority_stream)
     par = "1 gpu" if world == 1 else f"{world} gpus, one process each, tiles 2-D block-cyclic, RCCL p2p panel exchange (npw_comm_*)"
 
@@ -296,7 +298,7 @@ def main():
                 "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                 "config": {"workload": f"{n}x{n} fp64 Cholesky, {b}^2 tiles, {nb}x{nb} tile grid, alg_wrappers.cholesky "
                                        f"via LambdaPACK DAG ({nb*(nb+1)*(nb+2)//6} tasks)",
-                           "n": n, "tile": b, "streams": args.streams, "parallelism": par,
+                           "n": n, "tile": b, "streams": args.streams, "chain_cus": chain_cus, "parallelism": par,
                            "pct_fp64_mfma_peak": round(100 * value / (FP64_MFMA_PEAK_TFLOPS * args.gpus), 2)}}
         if world == 1:
             times = be.collect_kernel_times()
@@ -313,6 +315,12 @@ def main():
                                     "traffic_unit": "B/launch; from " + SYRK_TRAFFIC_SOURCE + ", not this run (algorithmic 5.37e8)",
                                     "launches": len(syrk), "avg_ms": round(avg_ms, 4),
                                     "algorithmic_flop_per_launch": 2 * b ** 3}
+                # launches of the same kernel on the 192-CU partition beside a chol on the other 64 (kernel_ms
+                # "syrk@rest" / "chol@chain") are not full-chip launches and stay out of the roofline average
+                part = times.get("syrk@rest", [])
+                if part:
+                    line["roofline"]["beside_chol"] = {"launches": len(part), "avg_ms": round(float(np.mean(part)), 4),
+                                                       "cus": be.compute_units - chain_cus}
                 line["kernel_ms"] = {k: round(float(np.mean(v)), 4) for k, v in times.items() if v}
             # parity guard at full size: || A - L L^T ||_F / || A ||_F over ALL tiles (device side)
             line["config"]["residual_all_tiles"] = cholesky_residual(be, X, meta["outputs"][0], nb, full=True)

@@ -174,6 +174,10 @@ int npw_dtrsm_rltn_inv_batched(int count, int64_t m, int64_t n, const double* L,
 size_t npw_dpotrf_lower_workspace_bytes(int64_t n);
 int npw_dpotrf_lower(int64_t n, const double* A, int64_t lda, double* Lout, int64_t ldl,
                      int32_t* info_dev, void* workspace, npw_stream_t stream);
+/* Compute units a stream must offer for npw_dpotrf_lower(n): the workgroups of the panel chain wait for one another,
+ * one per CU.  A stream from npw_stream_create_masked with fewer CUs makes npw_dpotrf_lower fail (NPW_ERR_ARG), never
+ * hang.  (The executor asks before it moves a chol task onto its masked chain stream, job_runner.py.) */
+int npw_dpotrf_lower_resident_cus(int64_t n);
 
 /* Householder QR with compact-WY T of the m x n matrix A, LAPACK
  * DGEQRT3 conventions (H_j = I - tau_j v_j v_j^T, beta = -sign(alpha)*norm):

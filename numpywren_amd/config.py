@@ -20,6 +20,12 @@ DEFAULTS = {
         # holds at once for 4096-row tiles (2 workgroups per CU x 256 CUs / 16 slabs); 128-leaf TSQR: 1046 ms with 16,
         # 949 ms with 32 (profiles/r02_qr_tsqr.md).
         "batch_tasks": 32,
+        # Compute units set aside for the panel chain while trailing updates are ready: a `chol` task that becomes
+        # ready while independent trailing updates are still queued runs on a stream masked to this many CUs, the
+        # updates issued next run on a stream masked to the others, and the one in-order stream resumes when the
+        # factorisation is done (job_runner.LambdaPackExecutor.run_chain).  64 = the 63 panel workgroups of a 4096^2
+        # tile + 1; the other 192 CUs hold a 1024-tile syrk in exactly 3 rounds.  0 = off.  $NUMPYWREN_AMD_CHAIN_CUS.
+        "chain_cus": 64,
     },
     "store": {
         "tier": "hbm",           # "hbm" (device memory) or "host" (pinned/pageable host memory)
@@ -46,6 +52,9 @@ def default():
     tier = os.environ.get("NUMPYWREN_AMD_STORE")
     if tier:
         cfg["store"]["tier"] = tier
+    chain = os.environ.get("NUMPYWREN_AMD_CHAIN_CUS")
+    if chain is not None and chain != "":
+        cfg["executor"]["chain_cus"] = int(chain)
     streams = os.environ.get("NUMPYWREN_AMD_STREAMS")
     if streams:
         cfg["executor"]["streams"] = int(streams)

@@ -1287,6 +1287,34 @@ int trsm_rec(const TrsmCtx& c, int64_t coff, int64_t n, bool touched) {
     return trsm_rec(c, coff + n1, n2, true);
 }
 
+// Compute units a launch on `s` can be resident on: the device's, or fewer for a stream created with a CU mask
+// (npw_stream_create_masked -- the executor's chain stream, which runs a tile's factorisation beside the trailing
+// updates of the previous step).  The panel chain's workgroups spin on messages from one another, so every launch of
+// the factorisation must fit the stream's CUs at one workgroup (150 KiB of LDS) per CU.
+int stream_cu_count(hipStream_t s) {
+    static const int device_cus = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }();
+    int cus = device_cus;
+    uint32_t mask[16] = {0};
+    const int words = (device_cus + 31) / 32;
+    if (s != nullptr && words <= 16) {
+        if (hipExtStreamGetCUMask(s, (uint32_t)words, mask) == hipSuccess) {
+            int bits = 0;
+            for (int w = 0; w < words; ++w) bits += __builtin_popcount(mask[w]);
+            if (bits > 0 && bits < cus) cus = bits;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    return cus;
+}
+
+inline int64_t potrf_resident_wgs(int64_t n) { return n <= NB ? 1 : 1 + ceil_div(n - NB, (int64_t)PGROWS); }
+
 // Right-looking blocked Cholesky with NB-wide panels: three launches per block column
 //   diag block (factor + invert, one workgroup) -> panel  P <- P inv(L_jj)^T  (in place, one GEMM) ->
 //   trailing update  A22 -= P P^T  (lower tiles only, one GEMM with K = NB).
@@ -1301,6 +1329,8 @@ int potrf_right(int64_t n, double* A, int64_t lda, int32_t* info, double* Winv, 
     static std::atomic<unsigned long long> call_counter{
         (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() & 0x3fffffffULL};
     const unsigned long long call_tag = (call_counter.fetch_add(1) + 1) << 20;
+    NPW_REQUIRE(potrf_resident_wgs(n) <= stream_cu_count(s), "potrf: the panel chain of a %lld^2 tile needs %lld resident workgroups, the stream has %d CUs",
+                (long long)n, (long long)potrf_resident_wgs(n), stream_cu_count(s));
     for (int64_t j0 = 0; j0 < n; j0 += NB) {
         const int64_t nb = (n - j0 < NB) ? n - j0 : NB;
         double* Ajj = A + j0 * lda + j0;
@@ -1356,12 +1386,7 @@ int potrf_lookahead(int64_t n, double* A, int64_t lda, int32_t* info, double* Wi
     static std::atomic<unsigned long long> call_counter{
         (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() & 0x3fffffffULL};
     const unsigned long long call_tag = (call_counter.fetch_add(1) + 1) << 20;
-    static const int num_cus = [] {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }();
+    const int num_cus = stream_cu_count(s);
     for (int64_t jb = 0; jb < steps; ++jb) {
         const int64_t j0 = jb * NB;
         const int64_t m = n - j0 - NB;
@@ -1374,7 +1399,7 @@ int potrf_lookahead(int64_t n, double* A, int64_t lda, int32_t* info, double* Wi
             const unsigned tiles = (unsigned)(t * (t + 1) / 2);
             wgs = std::max(wgs, std::min<unsigned>(std::max(strips, chain + tiles), (unsigned)num_cus));
         }
-        NPW_REQUIRE(chain <= (unsigned)num_cus, "potrf: block column needs %u resident workgroups, device has %d CUs", chain, num_cus);
+        NPW_REQUIRE(chain <= (unsigned)num_cus, "potrf: block column needs %u resident workgroups, the stream has %d CUs", chain, num_cus);
         hipLaunchKernelGGL(potrf_step_kernel, dim3(wgs), dim3(DIAG_THREADS), DIAG_LDS_BYTES, s, (int)n, A, lda, (int)j0, info,
                            Winv + w_block_offset(jb), msg, call_tag + (unsigned long long)jb * NJB + 1, ctl + jb * CTL_INTS);
         NPW_LAUNCH_CHECK();
@@ -1491,6 +1516,8 @@ int npw_dtrsm_rltn(int64_t m, int64_t n, const double* L, int64_t ldl, const dou
     if (rc) return rc;
     return npw_dtrsm_rltn_inv(m, n, L, ldl, Winv, B, ldb, X, ldx, static_cast<char*>(workspace) + winv_bytes(n), stream);
 }
+
+int npw_dpotrf_lower_resident_cus(int64_t n) { return n <= 0 ? 0 : (int)potrf_resident_wgs(n); }
 
 size_t npw_dpotrf_lower_workspace_bytes(int64_t n) {
     if (n <= 0) return 0;

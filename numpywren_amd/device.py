@@ -274,6 +274,42 @@ class HipBackend(object):
         _ffi.check(self.lib.npw_stream_create_masked(ctypes.byref(h), arr, words), "npw_stream_create_masked")
         return Stream(h.value, False, name)
 
+    def chain_streams(self, chain_cus):
+        """(chain, rest): a stream restricted to `chain_cus` compute units and one restricted to all the others, so that
+        a latency-bound kernel whose workgroups each need a whole CU (kernels.chol) runs BESIDE throughput kernels
+        instead of queueing behind their ~1 ms workgroups.  The chain takes the LEADING bits of the CU mask: the mask
+        bits are dealt round-robin over the XCDs, so both partitions get the same number of CUs in every XCD
+        (measured, tools/overlap_probe.py: with the leading 64 bits chol (2.86 ms) and a 1024-workgroup syrk on the
+        other 192 CUs (2.92 ms) finish together in 2.93 ms; a strided choice of bits gives no overlap at all)."""
+        chain_cus = int(chain_cus)
+        if not 0 < chain_cus < self.compute_units:
+            raise ValueError("chain_streams: chain_cus must be in (0, %d)" % self.compute_units)
+        with self._lock:
+            cached = getattr(self, "_chain_streams", {}).get(chain_cus)
+            if cached is None:
+                words = (self.compute_units + 31) // 32
+                lead, rest = [0] * words, [0] * words
+                for cu in range(self.compute_units):
+                    (lead if cu < chain_cus else rest)[cu // 32] |= 1 << (cu % 32)
+                made = []
+                for bits, name in ((lead, "chain"), (rest, "rest")):
+                    arr = (ctypes.c_uint32 * words)(*bits)
+                    h = ctypes.c_void_p(0)
+                    _ffi.check(self.lib.npw_stream_create_masked(ctypes.byref(h), arr, words), "npw_stream_create_masked")
+                    made.append(Stream(h.value, False, name))
+                cached = tuple(made)
+                if not hasattr(self, "_chain_streams"):
+                    self._chain_streams = {}
+                    self._partition_names = {}
+                self._chain_streams[chain_cus] = cached
+                for st in made:
+                    self._partition_names[st.handle] = st.name
+        return cached
+
+    def chol_resident_cus(self, n):
+        """Compute units a stream must offer for `chol` of an n x n tile (npw_dpotrf_lower_resident_cus)."""
+        return int(self.lib.npw_dpotrf_lower_resident_cus(int(n)))
+
     def _sh(self, stream):
         if stream is None:
             return self.default_stream.handle
@@ -360,7 +396,9 @@ class HipBackend(object):
             return
         ev1 = self.new_event(timing=True)
         self.record(ev1, sh)
-        self.kernel_timers[name].append((ev0, ev1))
+        # launches on a CU-masked partition (chain_streams) are kept apart: "syrk@rest", "chol@chain"
+        part = getattr(self, "_partition_names", {}).get(sh)
+        self.kernel_timers.setdefault(name if part is None else name + "@" + part, []).append((ev0, ev1))
 
     def collect_kernel_times(self):
         """{name: [milliseconds per launch]}; synchronises the device."""

@@ -89,6 +89,11 @@ class LambdaPackExecutor(object):
         self._rr = 0
         self.compiled = program.program
         self._readers_left = None
+        # chain partition (one in-order stream only): see run_chain
+        self.chain_cus = int(cfg.get("chain_cus", 0) or 0) if n == 1 and self.prio_stream is None else 0
+        if self.chain_cus and not (hasattr(self.be, "chain_streams") and 0 < self.chain_cus < getattr(self.be, "compute_units", 0)):
+            self.chain_cus = 0
+        self.chain_runs = 0
 
     # ---- stream choice ----
     def pick_stream(self, compute):
@@ -139,13 +144,88 @@ class LambdaPackExecutor(object):
                 if self._readers_left[r] == 0:
                     self.compiled.matrices[r[0]].delete_block(*r[1])
 
+    # ---- the panel chain beside trailing updates ----
+    def chain_companions(self, expr_idx, var_values):
+        """For a ready task whose kernel needs whole CUs and whose workgroups wait for one another (kernels.chol): the
+        ready throughput tasks (removed from the heap, best priority first) to issue beside it, or [] when the task
+        should run on the full chip (no chain partition configured, the tile's chain does not fit it, nothing else is
+        ready).  Ready tasks are independent of one another, so any of them may run concurrently with the chain."""
+        if not self.chain_cus:
+            return []
+        compute = self.compiled.kernel(expr_idx)
+        need = getattr(compute, "_npw_chain_resident_cus", None)
+        if need is None:
+            return []
+        task = self.compiled.task(expr_idx, var_values)
+        try:
+            m, idx = task.reads[0]
+            s0, e0 = self.compiled.matrices[m].__block_idx_to_real_idx__(idx)[0]
+            if need(self.be, int(e0 - s0)) > self.chain_cus:
+                return []
+        except Exception:
+            return []
+        # fill the window (weight 1.0) without running past it: the full chip waits for BOTH partitions.  Whole-window
+        # tasks first; lighter ones (a symmetric update: 0.69) only when no such task is ready.
+
+        def weigh(e2, v2):
+            w = getattr(self.compiled.kernel(e2), "_npw_chain_weight", None)
+            return None if w is None else w(self.compiled.task(e2, v2))
+
+        def pred_full(e2, v2):
+            w = weigh(e2, v2)
+            return w is not None and w >= 0.95
+
+        picked = self.program.dequeue_matching(pred_full, 1)
+        if picked:
+            return picked
+        total = [0.0]
+
+        def pred_light(e2, v2):
+            w = weigh(e2, v2)
+            if w is None or total[0] + w > 1.05:
+                return False
+            total[0] += w
+            return True
+
+        return self.program.dequeue_matching(pred_light, 8)
+
+    def is_chain_task(self, expr_idx):
+        return self.chain_cus > 0 and getattr(self.compiled.kernel(expr_idx), "_npw_chain_resident_cus", None) is not None
+
+    def run_chain(self, node, companions):
+        """`node` on the chain stream (chain_cus compute units), `companions` on the stream masked to the other CUs;
+        the in-order stream resumes when the chain task is done.  CDNA4 does not preempt and the chain's workgroups
+        need a CU's whole LDS, so sharing CUs with ~1 ms GEMM workgroups would stall every one of its launches
+        (profiles/r01_overlap_study.md); a static partition for the duration of the task does not.  Data dependencies
+        need nothing extra: tiles carry their producers' events across streams."""
+        be = self.be
+        full = self.streams[0]
+        chain, rest = be.chain_streams(self.chain_cus)
+        # both partitions start when the full chip has drained and the full chip resumes when both are done: the chain's
+        # CUs must stay free of ~1 ms GEMM workgroups, and two chip-filling GEMMs sharing CUs run slower than one after
+        # the other (measured: a 1024-tile and a 496-tile syrk side by side 3.65 ms, in sequence 3.0)
+        ev = be.record_new(full)
+        be.wait_event(chain, ev)
+        be.wait_event(rest, ev)
+        be.recycle_event(ev)
+        out = [self.run_task(node[0], node[1], stream=chain)]
+        for e, v in companions:
+            out.append(self.run_task(e, v, stream=rest))
+        for part in (chain, rest):
+            ev = be.record_new(part)
+            be.wait_event(full, ev)
+            be.recycle_event(ev)
+        self.chain_runs += 1
+        return out
+
     # ---- one task ----
-    def run_task(self, expr_idx, var_values):
+    def run_task(self, expr_idx, var_values, stream=None):
         t_enq = time.time()
         task = self.compiled.task(expr_idx, var_values)
         compute = self.compiled.kernel(expr_idx)
         mats = self.compiled.matrices
-        stream = self.pick_stream(compute)
+        if stream is None:
+            stream = self.pick_stream(compute)
         device_kernel = getattr(compute, "_npw_device_kernel", False)
         # A kernel whose workgroups need a whole CU to themselves (the Cholesky panel chain: 150 KiB of LDS each)
         # starves next to chip-filling GEMMs of other streams -- every launch then waits for ~1 ms workgroups to
@@ -332,7 +412,8 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
     inflight = collections.deque()
     program._defer_success = True
     if after:
-        for sh in list(ex.streams) + ([ex.prio_stream] if ex.prio_stream is not None else []):
+        chain_pair = list(be.chain_streams(ex.chain_cus)) if ex.chain_cus else []
+        for sh in list(ex.streams) + ([ex.prio_stream] if ex.prio_stream is not None else []) + chain_pair:
             for ev in after:
                 be.wait_event(sh, ev)
     try:
@@ -344,6 +425,13 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
                 program._enqueue(node)
                 break
             e, v = node
+            if ex.chain_cus and not ex.is_chain_task(e):
+                # with a chain partition a ready panel factorisation goes first: it then runs beside the trailing updates
+                # that are ready with it (equal critical-path priority would issue those first, in ready order)
+                first = program.dequeue_matching(lambda e2, v2: ex.is_chain_task(e2), 1)
+                if first:
+                    program._enqueue(node)
+                    e, v = first[0]
             t0 = time.time()
             if ex.batch_fn(e) is not None and getattr(ex.compiled.kernel(e), "_npw_batch_gather", False):
                 # A batched kind whose siblings become ready one at a time (the trsm tasks of a block column wait for
@@ -367,6 +455,26 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
                             inflight.append(last)
                     running_times.append((t0, time.time()))
                     continue
+            companions = ex.chain_companions(e, v)
+            if companions:
+                chain_group = [(e, v)] + companions
+                for ge, gv in chain_group:
+                    program.set_node_status(ge, gv, lp.NS.RUNNING)
+                try:
+                    lasts = ex.run_chain((e, v), companions)
+                except Exception as exc:
+                    program.handle_exception(exc, tb=traceback.format_exc(), expr_idx=e, var_values=v)
+                    raise
+                for ge, gv in chain_group:
+                    program.post_op(ge, gv, lp.PS.SUCCESS, None)
+                    program.set_node_status(ge, gv, lp.NS.FINISHED)
+                    executed.append([ge, gv])
+                    refs.append((ge, gv))
+                running_times.append((t0, time.time()))
+                for last in lasts:
+                    if last is not None and last.ready is not None:
+                        inflight.append(last)
+                continue
             # independent ready tasks of the same latency-bound kind (TSQR leaves, the nodes of a tree level) go to
             # the device as ONE batched launch sequence
             group = [(e, v)]
@@ -395,6 +503,8 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
         # completion marks of THIS run: one event per stream it used (a device-wide synchronise would also wait for
         # whatever a pipelining caller has enqueued behind it)
         used = list(ex.streams) + ([ex.prio_stream] if ex.prio_stream is not None else [])
+        if ex.chain_runs:
+            used += list(be.chain_streams(ex.chain_cus))
         marks = [be.record_new(sh) for sh in used] if hasattr(be, "record_new") and hasattr(be, "event_sync") else None
         program.completion_marks = list(marks) if (marks is not None and not wait) else []
 

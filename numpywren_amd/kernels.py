@@ -427,6 +427,15 @@ for _k in (chol, trsm, qr_factor, lq_factor):
 chol._npw_needs_whole_cus = True   # see job_runner.LambdaPackExecutor.run_task
 
 
+# The chain partition of the executor (job_runner.LambdaPackExecutor.run_chain): `chol` on a stream masked to a quarter
+# of the CUs, throughput kernels of the same tile size beside it on the rest.  Weights in units of that window,
+# measured at the 4096^2 tile (tools/overlap_probe.py): chol on 64 CUs 2.86 ms; on the other 192 a general trailing
+# update 2.92 ms, one whose x and y are the same tile (lower triangle + mirror, half the products) 2.0 ms.
+chol._npw_chain_resident_cus = lambda be, rows: be.chol_resident_cus(rows)
+syrk._npw_chain_weight = lambda task: 0.69 if len(task.reads) >= 3 and task.reads[1] == task.reads[2] else 1.0
+gemm._npw_chain_weight = lambda task: 1.0
+
+
 # ------------------------------------------------------------------------------------------------
 # surface kept for import compatibility; not on the gemm / cholesky / tsqr / bdfac paths
 # ------------------------------------------------------------------------------------------------

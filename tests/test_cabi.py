@@ -41,6 +41,9 @@ def test_version_and_error_string():
     assert lib.npw_dpotrf_lower_workspace_bytes(100) == winv // 8
     assert lib.npw_dpotrf_lower_workspace_bytes(4096) == winv
     assert lib.npw_dgeqrt_workspace_bytes(8192, 4096) > 4096 * 4096 * 8
+    # compute units the panel chain of an n x n factorisation has to be resident on (one workgroup per 64 rows below
+    # the 128-wide diagonal block, + 1): what a CU-masked stream must offer
+    assert [lib.npw_dpotrf_lower_resident_cus(n) for n in (0, 100, 128, 129, 1024, 4096, 8192)] == [0, 1, 1, 2, 15, 63, 127]
 
 
 def test_no_cpu_fallback():
