@@ -119,9 +119,10 @@ int npw_sgemm(char transA, char transB, int64_t m, int64_t n, int64_t k, float a
 
 /* D = S - X * Y^T   (S,D: m x n; X: m x k; Y: n x k).  D may alias S.
  * skip_x / skip_y: optional device flags (see npw_is_zero): if either is set D = S.
- * X == Y (same pointer and ld, m == n >= 256: the diagonal tiles of the trailing matrix): X X^T is
- * symmetric bit for bit, so only the tiles touching the lower triangle are computed and the strict
- * upper triangle of D is their transpose; S is then assumed symmetric (its lower triangle wins).
+ * X == Y (same pointer and ld, m == n >= 1024 a multiple of 128: the diagonal tiles of the trailing
+ * matrix): X X^T is symmetric bit for bit, so only the 128 x 128 tiles below the diagonal are multiplied
+ * and each of them also writes its mirror tile (S is read at both positions: the result is the full
+ * S - X X^T for any S, symmetric or not).
  * workspace: npw_dgemm_nt_sub_workspace_bytes(m, n, k) bytes (0 unless the symmetric path applies), may
  * be NULL: it lets the diagonal blocks of the symmetric path run k-split over the whole chip.
  * Replaces kernels.syrk (reference numpywren/kernels.py:212-215) -- the Cholesky
@@ -131,6 +132,15 @@ int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t l
                      const double* X, int64_t ldx, const double* Y, int64_t ldy, double* D,
                      int64_t ldd, const int32_t* skip_x, const int32_t* skip_y, void* workspace,
                      npw_stream_t stream);
+/* `count` (<= 16) independent updates D[z] = S[z] - X[z] * Y[z]^T of one shape as ONE launch: the ready trailing
+ * updates of a block column of the Cholesky DAG (one RemoteCall of kernels.syrk each, reference lambdapack.py:360-380)
+ * handed over together by the executor.  Arrays of `count` device pointers (16-byte aligned tiles; D[z] may alias
+ * S[z]); skip_x / skip_y: arrays of per-problem flags or both NULL.  Every problem is computed exactly as
+ * npw_dgemm_nt_sub computes it; X[z] == Y[z] gets no symmetric treatment here. */
+int npw_dgemm_nt_sub_batched(int count, int64_t m, int64_t n, int64_t k, const double* const* S, int64_t lds,
+                             const double* const* X, int64_t ldx, const double* const* Y, int64_t ldy,
+                             double* const* D, int64_t ldd, const int32_t* const* skip_x,
+                             const int32_t* const* skip_y, npw_stream_t stream);
 
 /* Solve X * L^T = B for X, L lower triangular n x n (non-unit), B and X m x n.
  * Only the lower triangle of L is read.  X may alias B.

@@ -115,6 +115,7 @@ struct GemmParams {
     int a_upper_tri;                                  // k range of row tile m0 starts at m0 (op(A) upper triangular)
     int use_delta;                                    // irregular batch: element offsets per problem instead of strides
     int64_t da[16], db[16], dc[16], dd[16];
+    int ds0[16], ds1[16];                             // ... and of the skip flags (int32 units)
 };
 
 // XCD-aware + grouped mapping of the linear block id to an output tile.
@@ -178,6 +179,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
         p.B += p_in.db[bz];
         if (p.C) p.C += p_in.dc[bz];
         p.D += p_in.dd[bz];
+        if (p.skip0) p.skip0 += p_in.ds0[bz];
+        if (p.skip1) p.skip1 += p_in.ds1[bz];
     } else if (gridDim.z > 1) {
         int64_t bz = blockIdx.z, b2 = 0;
         if (p.batch_inner > 0) {
@@ -225,6 +228,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
         tile_m += 1;
     } else {
         block_to_tile(p.tiles_m, p.tiles_n, spread, tile_m, tile_n);
+        // triangular B: the k range grows with the tile column -- longest tiles first, the short ones fill the tail
+        if (p.b_lower_tri) tile_n = p.tiles_n - 1 - tile_n;
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     if (p.lower_only && n0 > m0 + BM - 1) return;  // tile entirely above the diagonal
@@ -725,6 +730,8 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
             p.db[z] = (in && opts.delta_b) ? opts.delta_b[z] : (in ? (int64_t)z * opts.batch_b : 0);
             p.dc[z] = (in && opts.delta_c) ? opts.delta_c[z] : (in ? (int64_t)z * opts.batch_c : 0);
             p.dd[z] = (in && opts.delta_d) ? opts.delta_d[z] : (in ? (int64_t)z * opts.batch_d : 0);
+            p.ds0[z] = (in && opts.delta_skip0) ? opts.delta_skip0[z] : 0;
+            p.ds1[z] = (in && opts.delta_skip1) ? opts.delta_skip1[z] : 0;
         }
     }
     p.tag = opts.tag;
@@ -866,6 +873,53 @@ int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t l
         d.splitk_ws = workspace;
     }
     return npw::gemm<double>('N', 'T', 128, 128, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, d, npw::as_stream(stream));
+}
+
+// `count` independent trailing updates  D[z] = S[z] - X[z] Y[z]^T  of one shape as ONE launch (blockIdx.z = problem):
+// workgroups flow from one problem's tiles into the next one's, so the chip drains once per batch instead of once per
+// tile -- the fixed cost of a launch (first loads, the C / D traffic of the last round of workgroups, the drain:
+// 63 us of a 1.92 ms 4096^3 update, tools/gemm_fixed_cost.py) is paid once.  Each problem is computed exactly as
+// npw_dgemm_nt_sub computes it (same tiles, same order of products).  X[z] == Y[z] (the symmetric form) is not
+// batched: callers issue those tiles one by one.
+int npw_dgemm_nt_sub_batched(int count, int64_t m, int64_t n, int64_t k, const double* const* S, int64_t lds,
+                             const double* const* X, int64_t ldx, const double* const* Y, int64_t ldy, double* const* D,
+                             int64_t ldd, const int32_t* const* skip_x, const int32_t* const* skip_y, npw_stream_t stream) {
+    NPW_REQUIRE(count >= 0 && m >= 0 && n >= 0 && k >= 0, "npw_dgemm_nt_sub_batched: negative argument");
+    if (count == 0 || m == 0 || n == 0) return NPW_OK;
+    NPW_REQUIRE(count <= 16, "npw_dgemm_nt_sub_batched: at most 16 problems per call");
+    NPW_REQUIRE(S && X && Y && D, "npw_dgemm_nt_sub_batched: NULL argument");
+    NPW_REQUIRE((skip_x == nullptr) == (skip_y == nullptr), "npw_dgemm_nt_sub_batched: skip_x and skip_y go together");
+    int64_t da[16], db[16], dc[16], dd[16], ds0[16], ds1[16];
+    for (int z = 0; z < count; ++z) {
+        NPW_REQUIRE(S[z] && X[z] && Y[z] && D[z], "npw_dgemm_nt_sub_batched: NULL tile (problem %d)", z);
+        NPW_REQUIRE(((reinterpret_cast<uintptr_t>(S[z]) | reinterpret_cast<uintptr_t>(X[z]) | reinterpret_cast<uintptr_t>(Y[z]) |
+                      reinterpret_cast<uintptr_t>(D[z])) & 15) == 0, "npw_dgemm_nt_sub_batched: tiles must be 16-byte aligned");
+        da[z] = X[z] - X[0];
+        db[z] = Y[z] - Y[0];
+        dc[z] = S[z] - S[0];
+        dd[z] = D[z] - D[0];
+        ds0[z] = ds1[z] = 0;
+        if (skip_x) {
+            NPW_REQUIRE(skip_x[z] && skip_y[z], "npw_dgemm_nt_sub_batched: NULL skip flag (problem %d)", z);
+            ds0[z] = skip_x[z] - skip_x[0];
+            ds1[z] = skip_y[z] - skip_y[0];
+            NPW_REQUIRE(ds0[z] == (int)ds0[z] && ds1[z] == (int)ds1[z], "npw_dgemm_nt_sub_batched: skip flags too far apart");
+        }
+    }
+    npw::GemmOpts o;
+    o.tag = 1;
+    o.skip0 = skip_x ? skip_x[0] : nullptr;
+    o.skip1 = skip_y ? skip_y[0] : nullptr;
+    if (count > 1) {
+        o.batch = count;
+        o.delta_a = da;
+        o.delta_b = db;
+        o.delta_c = dc;
+        o.delta_d = dd;
+        o.delta_skip0 = ds0;
+        o.delta_skip1 = ds1;
+    }
+    return npw::gemm<double>('N', 'T', m, n, k, -1.0, X[0], ldx, Y[0], ldy, 1.0, S[0], lds, D[0], ldd, o, npw::as_stream(stream));
 }
 
 }  // extern "C"

@@ -71,6 +71,8 @@ struct GemmOpts {
     const int64_t* delta_b = nullptr;
     const int64_t* delta_c = nullptr;
     const int64_t* delta_d = nullptr;
+    const int64_t* delta_skip0 = nullptr;   // the same for the skip flags (int32 units)
+    const int64_t* delta_skip1 = nullptr;
 };
 
 // D = alpha * op(A) op(B) + beta * C

@@ -391,21 +391,24 @@ class HipBackend(object):
         self.record(ev, sh)
         return ev
 
-    def _toc(self, name, sh, ev0):
+    def _toc(self, name, sh, ev0, count=1):
         if ev0 is None:
             return
         ev1 = self.new_event(timing=True)
         self.record(ev1, sh)
         # launches on a CU-masked partition (chain_streams) are kept apart: "syrk@rest", "chol@chain"
         part = getattr(self, "_partition_names", {}).get(sh)
-        self.kernel_timers.setdefault(name if part is None else name + "@" + part, []).append((ev0, ev1))
+        # count > 1: one batched launch over `count` tiles -- reported as `count` entries of duration / count
+        self.kernel_timers.setdefault(name if part is None else name + "@" + part, []).append((ev0, ev1, count))
 
     def collect_kernel_times(self):
         """{name: [milliseconds per launch]}; synchronises the device."""
         self.synchronize()
         out = {}
         for name, pairs in (self.kernel_timers or {}).items():
-            out[name] = [self.elapsed_ms(a, b) for a, b in pairs]
+            out[name] = []
+            for a, b, count in pairs:
+                out[name] += [self.elapsed_ms(a, b) / count] * count
         self.kernel_timers = None
         return out
 
@@ -796,6 +799,51 @@ class HipBackend(object):
         self._toc(tname, sh, t0)
         self._produced(sh, out)
         return out
+
+    def syrk_batched(self, problems, stream=None, exact_zero=True):
+        """[S - X Y^T for (S, X, Y) in problems] for independent updates of one shape (the ready trailing updates of a
+        block column of the Cholesky DAG) as ONE launch (npw_dgemm_nt_sub_batched): the chip drains once per batch
+        instead of once per tile.  Same numbers as `syrk` on each.  Updates with X is Y (the symmetric path) and
+        anything that does not fit the batch are issued one by one."""
+        sh = self._sh(stream)
+        outs = [None] * len(problems)
+        group = []
+        for i, (S, X, Y) in enumerate(problems):
+            ok = all(t.ndim == 2 and t.dtype == _F64 for t in (S, X, Y)) and X.ptr != Y.ptr
+            if ok and group:
+                S0, X0, Y0 = problems[group[0]]
+                ok = S.shape == S0.shape and X.shape == X0.shape and Y.shape == Y0.shape
+            if ok and X.shape[1] == Y.shape[1] and S.shape == (X.shape[0], Y.shape[0]):
+                group.append(i)
+            else:
+                outs[i] = self.syrk(S, X, Y, stream, inplace=False, exact_zero=exact_zero)
+        for c0 in range(0, len(group), 16):
+            idxs = group[c0:c0 + 16]
+            if len(idxs) == 1:
+                S, X, Y = problems[idxs[0]]
+                outs[idxs[0]] = self.syrk(S, X, Y, stream, inplace=False, exact_zero=exact_zero)
+                continue
+            count = len(idxs)
+            m, k = problems[idxs[0]][1].shape
+            n = problems[idxs[0]][2].shape[0]
+            fxs = fys = None
+            if exact_zero:
+                fxs = [self.zero_flag(problems[i][1], sh) for i in idxs]
+                fys = [self.zero_flag(problems[i][2], sh) for i in idxs]
+            res = [self.empty((m, n), _F64) for _ in idxs]
+            for i, out in zip(idxs, res):
+                self._use(sh, problems[i][0], problems[i][1], problems[i][2], out)
+            arr = lambda ptrs: (ctypes.c_void_p * count)(*ptrs)
+            t0 = self._tic("syrk", sh)
+            _ffi.check(self.lib.npw_dgemm_nt_sub_batched(
+                count, m, n, k, arr([problems[i][0].ptr for i in idxs]), n, arr([problems[i][1].ptr for i in idxs]), k,
+                arr([problems[i][2].ptr for i in idxs]), k, arr([o.ptr for o in res]), n,
+                arr([f.ptr for f in fxs]) if fxs else None, arr([f.ptr for f in fys]) if fys else None, sh), "syrk_batched")
+            self._toc("syrk", sh, t0, count)
+            self._produced(sh, *res)
+            for i, out in zip(idxs, res):
+                outs[i] = out
+        return outs
 
     def trsm(self, L, Y, stream=None, exact_zero=True):
         """Y L^-T (kernels.trsm with x = L lower triangular)."""

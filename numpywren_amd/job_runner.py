@@ -94,6 +94,12 @@ class LambdaPackExecutor(object):
         if self.chain_cus and not (hasattr(self.be, "chain_streams") and 0 < self.chain_cus < getattr(self.be, "compute_units", 0)):
             self.chain_cus = 0
         self.chain_runs = 0
+        self.chain_stmts = []
+        if self.chain_cus:
+            self.chain_stmts = [i for i, k in getattr(self.compiled, "_kernels", {}).items()
+                                if getattr(k, "_npw_chain_resident_cus", None) is not None]
+            if not self.chain_stmts:
+                self.chain_cus = 0
 
     # ---- stream choice ----
     def pick_stream(self, compute):
@@ -475,8 +481,35 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
                     if last is not None and last.ready is not None:
                         inflight.append(last)
                 continue
-            # independent ready tasks of the same latency-bound kind (TSQR leaves, the nodes of a tree level) go to
-            # the device as ONE batched launch sequence
+            if ex.chain_cus and ex.batch_fn(e) is not None:
+                # before a batch swallows the ready tasks of this kind: the one whose completion makes a panel
+                # factorisation ready goes first and alone -- the factorisation then finds the others still queued and
+                # takes one of them along as its companion
+                first = [(e, v)] if any(program.enables(e, v, stmt) for stmt in ex.chain_stmts) else []
+                if not first:
+                    for stmt in ex.chain_stmts:
+                        first = program.dequeue_enablers(stmt, limit=1)
+                        if first:
+                            program._enqueue((e, v))
+                            break
+                if first:
+                    e, v = first[0]
+                    program.set_node_status(e, v, lp.NS.RUNNING)
+                    try:
+                        last = ex.run_task(e, v)
+                    except Exception as exc:
+                        program.handle_exception(exc, tb=traceback.format_exc(), expr_idx=e, var_values=v)
+                        raise
+                    program.post_op(e, v, lp.PS.SUCCESS, None)
+                    program.set_node_status(e, v, lp.NS.FINISHED)
+                    executed.append([e, v])
+                    refs.append((e, v))
+                    running_times.append((t0, time.time()))
+                    if last is not None and last.ready is not None:
+                        inflight.append(last)
+                    continue
+            # independent ready tasks of the same kind (TSQR leaves, the nodes of a tree level, the trailing updates of a
+            # block column) go to the device as ONE batched launch sequence
             group = [(e, v)]
             if ex.batch_fn(e) is not None:
                 group += program.dequeue_matching(lambda e2, v2: e2 == e, ex.batch_tasks - 1)

@@ -120,6 +120,29 @@ def _syrk_flops(s, x, y):
 syrk.flops = _syrk_flops
 
 
+def _syrk_batch(be, stream, arg_lists, kwargs_list):
+    """Ready syrk tasks of one statement (the trailing updates of a block column of the Cholesky DAG,
+    S[i+1, j, k] = syrk(S[i, j, k], O[j, i], O[k, i]), reference algs.py:248) as batched launches of up to 16 tiles
+    (HipBackend.syrk_batched); the diagonal ones (x is y) and anything that is not three fp64 device tiles one by one.
+    Same outputs as `syrk` for each task."""
+    exact = _ctx()[2]
+    out = [None] * len(arg_lists)
+    plain = []
+    for pos, (args, kw) in enumerate(zip(arg_lists, kwargs_list)):
+        if len(args) == 3 and not kw and all(isinstance(a, DeviceTile) and a.ndim == 2 and a.dtype == np.float64 for a in args):
+            plain.append(pos)
+        else:
+            out[pos] = _syrk(*args, **kw)
+    if plain:
+        res = be.syrk_batched([tuple(arg_lists[p]) for p in plain], stream, exact_zero=exact)
+        for p, r in zip(plain, res):
+            out[p] = r
+    return out
+
+
+syrk._npw_batch = _syrk_batch
+
+
 @_kernel
 def _trsm(be, stream, x, y, lower=False, right=True, *args, **kwargs):
     """Solve X . x^T = y, x lower triangular (reference kernels.py:254-257:

@@ -359,6 +359,20 @@ class LambdaPackProgram(object):
                 heapq.heapify(self._ready)
             return taken
 
+    def enables(self, e, v, expr_idx):
+        """True when task (e, v) is the LAST missing parent of a task of statement `expr_idx`."""
+        if e == expr_idx:
+            return False
+        with self._lock:
+            me = self._node_str(e, v)
+            for child in self.program.find_children(e, v):
+                if child[0] != expr_idx:
+                    continue
+                edges = self._edges.get(self._node_str(*child), ())
+                if me not in edges and len(edges) == len(self.program.find_parents(child[0], child[1])) - 1:
+                    return True
+        return False
+
     def dequeue_enablers(self, expr_idx, limit=64):
         """Ready tasks (removed from the heap, best priority first) whose completion makes a task of statement
         `expr_idx` ready -- i.e. they are the LAST missing parent of such a task.  The executor runs them before a
@@ -370,16 +384,7 @@ class LambdaPackProgram(object):
             taken, kept = [], []
             for item in items:
                 e, v = item[2]
-                ok = False
-                if len(taken) < limit and e != expr_idx:
-                    me = self._node_str(e, v)
-                    for child in self.program.find_children(e, v):
-                        if child[0] != expr_idx:
-                            continue
-                        edges = self._edges.get(self._node_str(*child), ())
-                        if me not in edges and len(edges) == len(self.program.find_parents(child[0], child[1])) - 1:
-                            ok = True
-                            break
+                ok = len(taken) < limit and self.enables(e, v, expr_idx)
                 (taken if ok else kept).append(item)
             if taken:
                 self._ready = kept

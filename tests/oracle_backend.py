@@ -144,6 +144,10 @@ class OracleBackend(object):
             return HostTile(oracle.syrk(S.array, X.array, Y.array))
         return HostTile(S.array - X.array @ Y.array.T)
 
+    def syrk_batched(self, problems, stream=None, exact_zero=True):
+        self.calls.append(("syrk_batched", len(problems)))
+        return [self.syrk(S, X, Y, stream, exact_zero=exact_zero) for S, X, Y in problems]
+
     def trsm_batched(self, L, Ys, stream=None, exact_zero=True):
         self.calls.append(("trsm_batched", len(Ys)))
         return [self.trsm(L, y, stream, exact_zero) for y in Ys]

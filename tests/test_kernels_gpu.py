@@ -514,3 +514,66 @@ def test_trsm_tasks_of_a_block_column_run_as_one_batch(hbm_store):
     ref = oracle.cholesky(A, b)
     np.testing.assert_allclose(L, ref, rtol=1e-10, atol=1e-10 * np.abs(ref).max())
     program.free()
+
+
+@pytest.mark.parametrize("m,n,k,count", [(256, 256, 256, 3), (384, 256, 128, 5), (1024, 1024, 512, 16), (200, 136, 72, 4)])
+def test_syrk_batched_equals_one_by_one(m, n, k, count):
+    """npw_dgemm_nt_sub_batched (independent trailing updates in separate allocations, one launch) against `syrk` on
+    each -- bit for bit: every problem runs the same tiles in the same order -- and against the oracle; one problem with
+    an all-zero x takes the reference's short-circuit (kernels.py:213-214) inside the batch."""
+    be = kernels.get_backend()
+    rng = np.random.default_rng(m + n + k + count)
+    probs = [(rng.standard_normal((m, n)), rng.standard_normal((m, k)), rng.standard_normal((n, k))) for _ in range(count)]
+    probs[1] = (probs[1][0], np.zeros((m, k)), probs[1][2])
+    junk = [be.fill_random((5 + i, 3), i) for i in range(3)]
+    tiles = [tuple(be.to_device(a) for a in pr) for pr in probs]
+    got = be.syrk_batched(tiles)
+    assert len(got) == count
+    for (S, X, Y), t, d in zip(probs, tiles, got):
+        one = be.to_host(be.syrk(*t))
+        assert np.array_equal(be.to_host(d), one)
+        np.testing.assert_allclose(one, oracle.syrk(S, X, Y), rtol=0, atol=1e-12 * k)
+    assert np.array_equal(be.to_host(got[1]), probs[1][0])
+    del junk
+
+
+def test_syrk_batched_mixed_kinds_fall_back_one_by_one():
+    """x is y (the symmetric path), another shape and fp32 operands are issued one by one inside syrk_batched."""
+    be = kernels.get_backend()
+    rng = np.random.default_rng(3)
+    S = rng.standard_normal((1024, 1024)); X = rng.standard_normal((1024, 256)); Y = rng.standard_normal((1024, 256))
+    S2 = rng.standard_normal((128, 128)); X2 = rng.standard_normal((128, 64))
+    dS, dX, dY, dS2, dX2 = (be.to_device(a) for a in (S, X, Y, S2, X2))
+    got = be.syrk_batched([(dS, dX, dY), (dS, dX, dX), (dS2, dX2, dX2), (dS, dY, dX)])
+    for d, ref in zip(got, (S - X @ Y.T, S - X @ X.T, S2 - X2 @ X2.T, S - Y @ X.T)):
+        np.testing.assert_allclose(be.to_host(d), ref, rtol=0, atol=1e-11)
+
+
+def test_trailing_updates_of_a_block_column_run_batched(hbm_store):
+    """kernels.syrk._npw_batch through the executor: the ready off-diagonal updates of a block column go out as batched
+    launches; the factor equals the oracle's tile Cholesky."""
+    from numpywren_amd import alg_wrappers, job_runner
+    from numpywren_amd import lambdapack as lp
+    from numpywren_amd.matrix import BigMatrix
+    from numpywren_amd.matrix_init import shard_matrix
+    be = kernels.get_backend()
+    rng = np.random.default_rng(78)
+    n, b = 1536, 256
+    G = rng.standard_normal((n, 64))
+    A = G @ G.T + n * np.eye(n)
+    X = BigMatrix("syrk_batch_chol", shape=A.shape, shard_sizes=(b, b))
+    shard_matrix(X, A)
+    program, meta = alg_wrappers.cholesky(X)
+    program.start()
+    res = job_runner.lambdapack_run(program, timeout=300)
+    program.wait()
+    assert program.program_status() == lp.PS.SUCCESS, program.exceptions
+    nb = n // b
+    assert len(res["executed_messages"]) == nb * (nb + 1) * (nb + 2) // 6
+    prof = program.get_all_profiling_info()
+    batched = [p for p in prof if p.get("kernel") == "syrk" and p.get("batch", 1) > 1]
+    assert batched, "no syrk task ran in a batch"
+    L = meta["outputs"][0].numpy()
+    ref = oracle.cholesky(A, b)
+    np.testing.assert_allclose(L, ref, rtol=1e-10, atol=1e-10 * np.abs(ref).max())
+    program.free()
