@@ -212,12 +212,29 @@ def test_bdfac_golden(hbm_store):
     assert program.program_status() == lp.PS.SUCCESS, program.exceptions
     assert len(res["executed_messages"]) == int(ALG["bdfac_16_4/ntasks"])
     L, R = meta["outputs"]
+
+    def signs_factor(got, ref):
+        # stricter than |got| == |ref|: the sign of a reflection flips a whole ROW (a reflection from the left: the QR
+        # sweeps) or a whole COLUMN (from the right: the LQ sweeps) of a tile, nothing else, so the sign pattern
+        # sign(got * ref) must be an outer product r c^T; a sign error inside a trailing update breaks that.  Entries
+        # that are ~0 in the reference carry no sign.
+        sig = np.abs(ref) > 1e-7
+        M = np.sign(got * ref) * sig
+        rows, cols = M.shape
+        for i in range(rows):
+            for k in range(i + 1, rows):
+                both = sig[i] & sig[k]
+                prod = M[i, both] * M[k, both]           # = r_i r_k for every shared column
+                assert prod.size == 0 or np.all(prod == prod[0]), (got, ref)
+
     for name in ("R_0_2_0", "R_1_2_1", "R_2_1_2", "R_3_0_3"):
         got = R.get_block(*[int(x) for x in name.split("_")[1:]])
         np.testing.assert_allclose(np.abs(got), np.abs(ALG[f"bdfac_16_4/{name}"]), atol=1e-9)
+        signs_factor(got, ALG[f"bdfac_16_4/{name}"])
     for name in ("L_0_2_1", "L_1_1_2", "L_2_0_3"):
         got = L.get_block(*[int(x) for x in name.split("_")[1:]])
         np.testing.assert_allclose(np.abs(got), np.abs(ALG[f"bdfac_16_4/{name}"]), atol=1e-9)
+        signs_factor(got, ALG[f"bdfac_16_4/{name}"])
 
 
 @pytest.mark.parametrize("n,b", [(16, 4), (128, 32), (192, 64)])
