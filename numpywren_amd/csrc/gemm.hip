@@ -115,7 +115,7 @@ struct GemmParams {
     int a_upper_tri;                                  // k range of row tile m0 starts at m0 (op(A) upper triangular)
     int use_delta;                                    // irregular batch: element offsets per problem instead of strides
     int64_t da[16], db[16], dc[16], dd[16];
-    int ds0[16], ds1[16];                             // ... and of the skip flags (int32 units)
+    int64_t ds0[16], ds1[16];                         // ... and of the skip flags (int32 units)
 };
 
 // XCD-aware + grouped mapping of the linear block id to an output tile.
@@ -903,7 +903,6 @@ int npw_dgemm_nt_sub_batched(int count, int64_t m, int64_t n, int64_t k, const d
             NPW_REQUIRE(skip_x[z] && skip_y[z], "npw_dgemm_nt_sub_batched: NULL skip flag (problem %d)", z);
             ds0[z] = skip_x[z] - skip_x[0];
             ds1[z] = skip_y[z] - skip_y[0];
-            NPW_REQUIRE(ds0[z] == (int)ds0[z] && ds1[z] == (int)ds1[z], "npw_dgemm_nt_sub_batched: skip flags too far apart");
         }
     }
     npw::GemmOpts o;
