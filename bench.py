@@ -194,6 +194,13 @@ class Runner(object):
             job_runner.lambdapack_run(program, pipeline_width=self.streams, timeout=3600, wait=False, after=marks)
             self.settle()
             self.pending.append((program, meta))
+            if os.environ.get("NPW_BENCH_DEBUG"):
+                be = self.be
+                print(f"[bench] allocated {be.allocated_bytes / 2**30:.1f} GiB, pooled {be.pooled_bytes / 2**30:.1f}, peak "
+                      f"{be.peak_bytes / 2**30:.1f}, spilled {be.spilled_bytes_total / 2**30:.1f}, restored "
+                      f"{be.restored_bytes_total / 2**30:.1f}", file=sys.stderr)
+                print("        pool: " + ", ".join(f"{k / 2**20:.0f}MiB x{len(v)}" for k, v in sorted(be._free.items()) if v and k >= 2**26),
+                      "| pending:", len(be._pending), file=sys.stderr)
         else:
             from numpywren_amd import dist
             dist.lambdapack_run_distributed(program, self.comm, pipeline_width=self.streams, timeout=3600)

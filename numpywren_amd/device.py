@@ -202,6 +202,9 @@ class HipBackend(object):
         _ffi.check(self.lib.npw_device_info(device, name, 128, ctypes.byref(mem), ctypes.byref(cus), ctypes.byref(khz)))
         self.arch = name.value.decode()
         self.total_mem = mem.value
+        # the pool's own ceiling (see _alloc_raw): a little below the device's memory, which other allocations (RCCL,
+        # the runtime's code objects and queues) share.  $NUMPYWREN_AMD_ALLOC_LIMIT (bytes) overrides; 0 = none.
+        self.alloc_limit_bytes = int(os.environ.get("NUMPYWREN_AMD_ALLOC_LIMIT", int(0.94 * mem.value)))
         self.compute_units = cus.value
         self.clock_khz = khz.value
         self._lock = threading.RLock()
@@ -426,19 +429,38 @@ class HipBackend(object):
                 if lst:
                     self.pooled_bytes -= nbytes
                     return lst.pop(), nbytes
+            # A new block from the driver.  Keep the process inside the device's memory: hipMalloc does not fail at
+            # the physical limit (it over-commits into host memory and every kernel that touches such a block crawls),
+            # so the pool enforces one itself.  Near it, (1) wait for a released block of this size whose last users
+            # are still running -- a pipelining caller releases step i's tiles while step i + 1 is already queued on
+            # the same streams -- and (2) hand cached blocks of other sizes back to the driver.
+            limit = self.alloc_limit_bytes
+            if limit and self.allocated_bytes + nbytes > limit:
+                for idx, (ptr, nb, events) in enumerate(self._pending):
+                    if nb == nbytes:
+                        for e in events:
+                            self.event_sync(e)
+                            self._event_pool.append(e)
+                        del self._pending[idx]
+                        return ptr, nbytes
+                self._trim_locked()
+        over = bool(limit) and self.allocated_bytes + nbytes > limit
         p = ctypes.c_void_p(0)
-        rc = self.lib.npw_malloc(ctypes.byref(p), nbytes)
+        rc = -1 if over else self.lib.npw_malloc(ctypes.byref(p), nbytes)
         if rc != 0:
             # out of memory: give everything cached back to the driver and retry; then let the store push
             # least-recently-used tiles out to pinned host memory and retry once more
             self.synchronize()
             self.trim()
-            rc = self.lib.npw_malloc(ctypes.byref(p), nbytes)
+            over = bool(limit) and self.allocated_bytes + nbytes > limit
+            rc = -1 if over else self.lib.npw_malloc(ctypes.byref(p), nbytes)
             if rc != 0 and self.oom_handlers:
                 if sum(h(nbytes) for h in list(self.oom_handlers)) > 0:
                     self.synchronize()
                     self.trim()
                     rc = self.lib.npw_malloc(ctypes.byref(p), nbytes)
+            if rc != 0 and over:
+                rc = self.lib.npw_malloc(ctypes.byref(p), nbytes)   # nothing left to give back: let the driver decide
             _ffi.check(rc, f"npw_malloc({nbytes})")
         with self._lock:
             self.allocated_bytes += nbytes
@@ -470,16 +492,19 @@ class HipBackend(object):
                 self._free.setdefault(nbytes, []).append(ptr)
                 self.pooled_bytes += nbytes
 
+    def _trim_locked(self):
+        self._drain_pending()
+        for nbytes, lst in self._free.items():
+            for ptr in lst:
+                self.lib.npw_free(ptr)
+                self.allocated_bytes -= nbytes
+        self._free = {}
+        self.pooled_bytes = 0
+
     def trim(self):
         """Return all cached (unused) buffers to the driver."""
         with self._lock:
-            self._drain_pending()
-            for nbytes, lst in self._free.items():
-                for ptr in lst:
-                    self.lib.npw_free(ptr)
-                    self.allocated_bytes -= nbytes
-            self._free = {}
-            self.pooled_bytes = 0
+            self._trim_locked()
 
     def alloc(self, nbytes):
         ptr, real = self._alloc_raw(nbytes)
