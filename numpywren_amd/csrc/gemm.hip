@@ -877,8 +877,7 @@ int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t l
 
 // `count` independent trailing updates  D[z] = S[z] - X[z] Y[z]^T  of one shape as ONE launch (blockIdx.z = problem):
 // workgroups flow from one problem's tiles into the next one's, so the chip drains once per batch instead of once per
-// tile -- the fixed cost of a launch (first loads, the C / D traffic of the last round of workgroups, the drain:
-// 63 us of a 1.92 ms 4096^3 update, tools/gemm_fixed_cost.py) is paid once.  Each problem is computed exactly as
+// tile (measured: 1.917 -> 1.882 ms per 4096^3 update in launches of 16, profiles/r02_syrk_launch_forms.md).  Each problem is computed exactly as
 // npw_dgemm_nt_sub computes it (same tiles, same order of products).  X[z] == Y[z] (the symmetric form) is not
 // batched: callers issue those tiles one by one.
 int npw_dgemm_nt_sub_batched(int count, int64_t m, int64_t n, int64_t k, const double* const* S, int64_t lds,
