@@ -184,6 +184,15 @@ int npw_dtrsm_rltn_inv_batched(int count, int64_t m, int64_t n, const double* L,
 size_t npw_dpotrf_lower_workspace_bytes(int64_t n);
 int npw_dpotrf_lower(int64_t n, const double* A, int64_t lda, double* Lout, int64_t ldl,
                      int32_t* info_dev, void* workspace, npw_stream_t stream);
+/* The same factorisation, leaving only the inverses of the 128 x 128 diagonal blocks in `workspace`: a factor nobody
+ * solves with (the last diagonal tile of a matrix) never pays for the rest, and one that is produced beside other work
+ * on a few CUs leaves it to its first consumer.  npw_dtrtri_complete(n, Lout, ldl, workspace, stream) then turns the
+ * cache into what npw_dpotrf_lower leaves / npw_dtrsm_rltn_inv[_batched] expects (idempotent: it recomputes the same
+ * values).  Reference: kernels.chol / kernels.trsm, numpywren/kernels.py:225-226, 254-257. */
+int npw_dpotrf_lower_blocks(int64_t n, const double* A, int64_t lda, double* Lout, int64_t ldl,
+                            int32_t* info_dev, void* workspace, npw_stream_t stream);
+int npw_dtrtri_complete(int64_t n, const double* L, int64_t ldl, double* Winv, npw_stream_t stream);
+
 /* Compute units a stream must offer for npw_dpotrf_lower(n): the workgroups of the panel chain wait for one another,
  * one per CU.  A stream from npw_stream_create_masked with fewer CUs makes npw_dpotrf_lower fail (NPW_ERR_ARG), never
  * hang.  (The executor asks before it moves a chol task onto its masked chain stream, job_runner.py.) */

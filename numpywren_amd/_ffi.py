@@ -75,6 +75,8 @@ PROTOTYPES = {
     "npw_dpotrf_lower_workspace_bytes": (_sz, [_i64]),
     "npw_dpotrf_lower": (c_int, [_i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "npw_dpotrf_lower_resident_cus": (c_int, [_i64]),
+    "npw_dpotrf_lower_blocks": (c_int, [_i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "npw_dtrtri_complete": (c_int, [_i64, _vp, _i64, _vp, _vp]),
     "npw_dgeqrt_workspace_bytes": (_sz, [_i64, _i64]),
     "npw_dgeqrt": (c_int, [_i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "npw_dtpqrt_batched_workspace_bytes": (_sz, [c_int, _i64]),

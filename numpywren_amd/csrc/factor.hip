@@ -9,7 +9,8 @@
 //               diagonal block (factor + invert, one workgroup, LDS-resident)  ->  panel P <- P inv(L_jj)^T
 //               (one in-place GEMM)  ->  trailing update A22 -= P P^T (one GEMM over the lower tiles only).
 //   trsm(X,L):  recursive:  X1 = trsm(X1, L11);  X2 -= X1 * L21^T;  X2 = trsm(X2, L22)
-//               leaf:  X_j = X_j * inv(L_jj)^T   (GEMM with the cached inverse of the NB x NB diagonal block)
+//               leaf:  X_j = X_j * inv(L_jj)^T   (GEMM with the cached inverse of a diagonal block: 1024-wide groups
+//               as two independent products, 512-wide halves, NB-wide blocks next to ragged ends / in place)
 //
 // The NB x NB (128) diagonal blocks are handled by one workgroup each, entirely in LDS, as a blocked
 // algorithm over 16 x 16 sub-blocks with look-ahead between the waves (see potrf_diag_kernel).  The 16 x 16
@@ -38,11 +39,15 @@ constexpr int W_ELEMS = NJB * JB * WLD;
 constexpr size_t DIAG_LDS_BYTES = (size_t)(S_ELEMS + W_ELEMS + 2) * sizeof(double);  // 150,544 B
 constexpr int DIAG_THREADS = 512;
 // The inverses of L's diagonal blocks ("Winv") live in groups of LW x LW (row-major, ld = LW): group g covers
-// the diagonal blocks 4g .. 4g+3 of size NB at (q NB, q NB) inside it.  The diagonal kernels fill the NB x NB
-// blocks; complete_groups() then fills the rest of the lower triangle of every *full* group, so a group
-// is inv(L[g LW : (g+1) LW, same]) and the solve can use LW-wide leaves.  Everything above the diagonal is
-// zero (memset once).  After the groups comes scratch for complete_groups (LW/2 x LW/2 per group).
-constexpr int LW = 512;
+// the diagonal blocks WPG g .. WPG g + WPG - 1 of size NB at (q NB, q NB) inside it.  The diagonal kernels fill the
+// NB x NB blocks; complete_groups() then fills the rest of the lower triangle by doubling (every 2^k NB-wide pair that
+// lies inside the matrix), so a full group is inv(L[g LW : (g+1) LW, same]) and each of its HW-wide halves the
+// inverse of its own diagonal block.  The solve multiplies a whole group at a time (trsm_rec) or, next to a ragged
+// end, an HW-wide half.  Everything above the diagonal is zero (memset once).  After the groups comes scratch for
+// complete_groups (LW/2 x LW/2 per group).  (The error of a group's solve grows with cond of that 1024-wide block of
+// L, not of the tile: tests/test_kernels_gpu.py::test_chol_trsm_ill_conditioned.)
+constexpr int LW = 1024;
+constexpr int HW = LW / 2;    // a group's two diagonal halves are complete inverses of their own (the solve's leaves)
 constexpr int WPG = LW / NB;  // diagonal blocks per group
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
@@ -1177,18 +1182,20 @@ inline size_t winv_bytes(int64_t n) {
     return (winv_group_elems(n) + (size_t)ceil_div(n, LW) * (LW / 2) * (LW / 2)) * sizeof(double);
 }
 
-// Fill the off-diagonal part of every full LW x LW group of Winv by two doubling steps (batched GEMMs):
-//   inv [L11 0; L21 L22] = [X11 0; -X22 L21 X11, X22]     NB -> 2 NB (two pairs per group) -> LW
+// Fill the off-diagonal part of every LW x LW group of Winv by doubling steps (batched GEMMs):
+//   inv [L11 0; L21 L22] = [X11 0; -X22 L21 X11, X22]     NB -> 2 NB -> 4 NB (= HW) -> LW
 // Zeroes Winv's groups first?  No: the caller memsets before the diagonal kernels run.
 int complete_groups(int64_t n, const double* L, int64_t ldl, double* Winv, hipStream_t s) {
-    const int groups = (int)(n / LW);  // full groups only; a ragged tail keeps NB-wide leaves
-    if (groups == 0) return NPW_OK;
     double* T = Winv + winv_group_elems(n);
     const int64_t tstride = (LW / 2) * (LW / 2);
     for (int half = NB; half < LW; half *= 2) {
         const int pairs = LW / (2 * half);  // pairs per group
+        // every pair that lies inside the matrix: a ragged last group takes part in the levels it is wide enough for
+        // (a 512-wide tail still gets its 512 x 512 inverse), problem z = (group z / pairs, pair z % pairs)
+        const int total = (int)(n / (2 * half));
+        if (total == 0) break;
         GemmOpts o;
-        o.batch = groups * pairs;
+        o.batch = total;
         o.batch_inner = pairs;
         // T = L21 * X11      (half x half each, problem (g, h))
         o.batch_a = (int64_t)LW * (ldl + 1);
@@ -1260,17 +1267,36 @@ inline GemmOpts trsm_batch(const TrsmCtx& c, const int64_t* da, const int64_t* d
 // solve the column range [coff, coff + n) (relative to the panel); `touched`: its current values are in T
 int trsm_rec(const TrsmCtx& c, int64_t coff, int64_t n, bool touched) {
     const int64_t col = c.c0 + coff;  // absolute column inside L
-    const bool group_leaf = (n == LW && col % LW == 0 && c.groups_ready);
-    if (n <= NB || group_leaf) {
-        const double* Wb = group_leaf ? c.Winv + (size_t)(col / LW) * LW * LW : c.Winv + w_block_offset(col / NB);
+    // the column block still holds its right-hand side in X itself (first block of an in-place solve): NB-wide leaves only
+    const bool inplace0 = !touched && (const void*)c.B == (const void*)c.X;
+    const double* src = touched ? c.T + coff : c.B + coff;   // current values of the block
+    const int64_t lds = touched ? c.ldt : c.ldb;
+    const int64_t* dsrc = touched ? c.dT : c.dB;
+    if (c.groups_ready && !inplace0 && n == LW && col % LW == 0) {
+        // A whole group: X = src * inv(L_group)^T with the group's explicit inverse  W = [W11 0; W21 W22],
+        // W21 = -W22 L21 W11, in two independent products (instead of leaf, update, leaf):
+        //   X_lo = src_lo W11^T,     X_hi = [src_lo src_hi] [W21 W22]^T
+        // the same flops in fewer, longer-k launches; both read `src`, none reads the other's result.
+        const double* Wg = c.Winv + (size_t)(col / LW) * LW * LW;
+        GemmOpts lo = trsm_batch(c, dsrc, nullptr, c.dX);
+        lo.b_lower_tri = true;   // W11 lower triangular: column tile n0 stops at k = n0 + BN
+        int rc = gemm<double>('N', 'T', c.m, HW, HW, 1.0, src, lds, Wg, LW, 0.0, nullptr, 0, c.X + coff, c.ldx, lo, c.s);
+        if (rc) return rc;
+        GemmOpts hi = trsm_batch(c, dsrc, nullptr, c.dX);
+        hi.b_lower_tri = true;   // W22 lower triangular behind the HW columns of W21
+        hi.b_tri_offset = HW;
+        return gemm<double>('N', 'T', c.m, HW, LW, 1.0, src, lds, Wg + (size_t)HW * LW, LW, 0.0, nullptr, 0, c.X + coff + HW, c.ldx,
+                            hi, c.s);
+    }
+    const bool half_leaf = c.groups_ready && !inplace0 && n == HW && col % HW == 0;
+    if (n <= NB || half_leaf) {
+        const double* Wb = half_leaf ? c.Winv + (size_t)(col / LW) * LW * LW + ((col % LW) ? (size_t)HW * (LW + 1) : 0)
+                                     : c.Winv + w_block_offset(col / NB);
         double* Xj = c.X + coff;
-        GemmOpts o = trsm_batch(c, touched ? c.dT : c.dB, nullptr, c.dX);
-        o.b_lower_tri = group_leaf;  // inv(L_group) is lower triangular: column tile n0 stops at k = n0 + BN
-        if (touched)
-            return gemm<double>('N', 'T', c.m, n, n, 1.0, c.T + coff, c.ldt, Wb, LW, 0.0, nullptr, 0, Xj, c.ldx, o, c.s);
-        if ((const void*)c.B != (const void*)c.X)
-            return gemm<double>('N', 'T', c.m, n, n, 1.0, c.B + coff, c.ldb, Wb, LW, 0.0, nullptr, 0, Xj, c.ldx, o, c.s);
-        NPW_REQUIRE(!group_leaf && c.count == 1, "trsm: in-place panels use NB-wide leaves and are not batched");
+        GemmOpts o = trsm_batch(c, dsrc, nullptr, c.dX);
+        o.b_lower_tri = half_leaf;  // inv(L_half) is lower triangular: column tile n0 stops at k = n0 + BN
+        if (!inplace0) return gemm<double>('N', 'T', c.m, n, n, 1.0, src, lds, Wb, LW, 0.0, nullptr, 0, Xj, c.ldx, o, c.s);
+        NPW_REQUIRE(c.count == 1, "trsm: in-place solves are not batched");
         o.inplace_a = true;  // in-place solve of the first block of an in-place panel (row-panel tiling)
         return gemm<double>('N', 'T', c.m, n, n, 1.0, Xj, c.ldx, Wb, LW, 0.0, nullptr, 0, Xj, c.ldx, o, c.s);
     }
@@ -1524,8 +1550,28 @@ size_t npw_dpotrf_lower_workspace_bytes(int64_t n) {
     return winv_bytes(n);  // the block inverses (kept with the factor for its trsm consumers) + their scratch
 }
 
+static int potrf_lower_impl(int64_t n, const double* A, int64_t lda, double* Lout, int64_t ldl, int32_t* info_dev,
+                            void* workspace, npw_stream_t stream, bool complete);
+
 int npw_dpotrf_lower(int64_t n, const double* A, int64_t lda, double* Lout, int64_t ldl,
                      int32_t* info_dev, void* workspace, npw_stream_t stream) {
+    return potrf_lower_impl(n, A, lda, Lout, ldl, info_dev, workspace, stream, true);
+}
+
+int npw_dpotrf_lower_blocks(int64_t n, const double* A, int64_t lda, double* Lout, int64_t ldl,
+                            int32_t* info_dev, void* workspace, npw_stream_t stream) {
+    return potrf_lower_impl(n, A, lda, Lout, ldl, info_dev, workspace, stream, false);
+}
+
+int npw_dtrtri_complete(int64_t n, const double* L, int64_t ldl, double* Winv, npw_stream_t stream) {
+    NPW_REQUIRE(n >= 0, "npw_dtrtri_complete: negative dimension");
+    if (n == 0) return NPW_OK;
+    NPW_REQUIRE(L && Winv && ldl >= n, "npw_dtrtri_complete: bad argument");
+    return complete_groups(n, L, ldl, Winv, as_stream(stream));
+}
+
+static int potrf_lower_impl(int64_t n, const double* A, int64_t lda, double* Lout, int64_t ldl, int32_t* info_dev,
+                            void* workspace, npw_stream_t stream, bool complete) {
     NPW_REQUIRE(n >= 0, "npw_dpotrf_lower: negative dimension");
     NPW_REQUIRE(info_dev != nullptr, "npw_dpotrf_lower: info is NULL");
     hipStream_t s = as_stream(stream);
@@ -1550,7 +1596,7 @@ int npw_dpotrf_lower(int64_t n, const double* A, int64_t lda, double* Lout, int6
     NPW_HIP_CHECK(hipMemsetAsync(Winv, 0, winv_group_elems(n) * sizeof(double), s));
     rc = lookahead_applies(n) ? potrf_lookahead(n, Lout, ldl, info_dev, Winv, s) : potrf_right(n, Lout, ldl, info_dev, Winv, s);
     if (rc) return rc;
-    return complete_groups(n, Lout, ldl, Winv, s);  // the factor's trsm consumers use LW-wide leaves
+    return complete ? complete_groups(n, Lout, ldl, Winv, s) : NPW_OK;  // the factor's trsm consumers use LW-wide leaves
 }
 
 #ifdef NPW_DIAG_STAMPS

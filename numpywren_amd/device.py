@@ -870,6 +870,35 @@ class HipBackend(object):
                 outs[i] = out
         return outs
 
+    def _diag_inv(self, L, n, sh):
+        """The inverse cache of the factor tile L (inverses of its diagonal blocks in 1024-wide groups), ready for a
+        solve on stream `sh`: computed once per factor and shared by every trsm task that uses it (a whole block column
+        of the Cholesky DAG).  `chol` leaves the 128 x 128 block inverses with the factor; the groups are completed
+        here, by the first solve -- a factor nobody solves with never pays for them."""
+        aux = L.buf.aux if L.buf.aux is not None else {}
+        cached = aux.get("diag_inv") if L.offset == 0 else None   # the cache belongs to the tile at the buffer's start
+        if cached is None:
+            winv = self.alloc(max(16, self.lib.npw_dtrtri_diag_bytes(n)))
+            winv.streams.add(sh)
+            _ffi.check(self.lib.npw_dtrtri_diag(n, L.ptr, n, winv.ptr, sh), "trtri_diag")
+            cached = (winv, (self.record_new(sh), sh))
+            if L.offset == 0:
+                aux["diag_inv"] = cached
+                aux["diag_inv_complete"] = True
+                L.buf.aux = aux
+        elif aux.get("diag_inv_complete") is False:
+            winv = cached[0]
+            winv.streams.add(sh)
+            _ffi.check(self.lib.npw_dtrtri_complete(n, L.ptr, n, winv.ptr, sh), "trtri_complete")
+            cached = (winv, (self.record_new(sh), sh))
+            aux["diag_inv"] = cached
+            aux["diag_inv_complete"] = True
+        winv, ready = cached
+        if ready is not None and ready[1] != sh:
+            self.wait_event(sh, ready[0])
+        winv.streams.add(sh)
+        return winv
+
     def trsm(self, L, Y, stream=None, exact_zero=True):
         """Y L^-T (kernels.trsm with x = L lower triangular)."""
         self._require_2d(L, "trsm(x)")
@@ -884,20 +913,7 @@ class HipBackend(object):
         self._use(sh, L, Y, out)
         # the inverses of L's diagonal blocks are computed once per factor and shared by every trsm
         # task that uses it (a whole block column of the Cholesky DAG)
-        aux = L.buf.aux if L.buf.aux is not None else {}
-        cached = aux.get("diag_inv") if L.offset == 0 else None   # the cache belongs to the tile at the buffer's start
-        if cached is None:
-            winv = self.alloc(max(16, self.lib.npw_dtrtri_diag_bytes(n)))
-            winv.streams.add(sh)
-            _ffi.check(self.lib.npw_dtrtri_diag(n, L.ptr, n, winv.ptr, sh), "trtri_diag")
-            cached = (winv, (self.record_new(sh), sh))
-            if L.offset == 0:
-                aux["diag_inv"] = cached
-                L.buf.aux = aux
-        winv, ready = cached
-        if ready is not None and ready[1] != sh:
-            self.wait_event(sh, ready[0])
-        winv.streams.add(sh)
+        winv = self._diag_inv(L, n, sh)
         ws = self.alloc(max(16, self.lib.npw_dtrsm_rltn_inv_workspace_bytes(m, n)))
         ws.streams.add(sh)
         t0 = self._tic("trsm", sh)
@@ -928,20 +944,7 @@ class HipBackend(object):
         Xbuf.streams.add(sh)
         outs = [DeviceTile(Xbuf, (m, n), _F64, z * tb) for z in range(count)]
         self._use(sh, L, *Ys)
-        aux = L.buf.aux if L.buf.aux is not None else {}
-        cached = aux.get("diag_inv") if L.offset == 0 else None
-        if cached is None:
-            winv = self.alloc(max(16, self.lib.npw_dtrtri_diag_bytes(n)))
-            winv.streams.add(sh)
-            _ffi.check(self.lib.npw_dtrtri_diag(n, L.ptr, n, winv.ptr, sh), "trtri_diag")
-            cached = (winv, (self.record_new(sh), sh))
-            if L.offset == 0:
-                aux["diag_inv"] = cached
-                L.buf.aux = aux
-        winv, ready = cached
-        if ready is not None and ready[1] != sh:
-            self.wait_event(sh, ready[0])
-        winv.streams.add(sh)
+        winv = self._diag_inv(L, n, sh)
         ws = self.alloc(max(16, count * self.lib.npw_dtrsm_rltn_inv_workspace_bytes(m, n)))
         ws.streams.add(sh)
         pb = (ctypes.c_void_p * count)(*[y.ptr for y in Ys])
@@ -972,11 +975,12 @@ class HipBackend(object):
         ws.streams.add(sh)
         self._use(sh, A, out)
         t0 = self._tic("chol", sh)
-        _ffi.check(self.lib.npw_dpotrf_lower(n, A.ptr, n, out.ptr, n, info.ptr, ws.ptr, sh), "chol")
+        _ffi.check(self.lib.npw_dpotrf_lower_blocks(n, A.ptr, n, out.ptr, n, info.ptr, ws.ptr, sh), "chol")
         self._toc("chol", sh, t0)
         self._produced(sh, out)
-        # the workspace starts with the inverses of the factor's diagonal blocks: keep them with L
-        out.buf.aux = {"diag_inv": (ws, None)}
+        # the workspace starts with the inverses of the factor's diagonal blocks: keep them with L.  The wider inverse
+        # groups the solves multiply with are completed by the first trsm that uses the factor (_diag_inv)
+        out.buf.aux = {"diag_inv": (ws, None), "diag_inv_complete": False}
         return out, info
 
     def add_n(self, tiles, stream=None):

@@ -33,12 +33,12 @@ def test_version_and_error_string():
     # argument validation happens before any HIP call, so it is testable on a CPU-only box
     rc = lib.npw_dgemm(b"X", b"N", 4, 4, 4, 1.0, None, 4, None, 4, 0.0, None, 4, None, 4, None, None)
     assert rc == _ffi.NPW_ERR_ARG and b"transA" in lib.npw_last_error()
-    # inverse cache: one 512 x 512 group (+ a 256 x 256 scratch) per 512 columns, opaque to the caller
-    winv = 8 * (512 * 512 + 256 * 256) * 8
+    # inverse cache: one 1024 x 1024 group (+ a 512 x 512 scratch) per 1024 columns, opaque to the caller
+    winv = 4 * (1024 * 1024 + 512 * 512) * 8
     assert lib.npw_dtrtri_diag_bytes(4096) == winv
     assert lib.npw_dtrtri_diag_bytes(0) == 0
     assert lib.npw_dtrsm_rltn_workspace_bytes(4096, 4096) == winv + 4096 * 4096 * 8
-    assert lib.npw_dpotrf_lower_workspace_bytes(100) == winv // 8
+    assert lib.npw_dpotrf_lower_workspace_bytes(100) == winv // 4
     assert lib.npw_dpotrf_lower_workspace_bytes(4096) == winv
     assert lib.npw_dgeqrt_workspace_bytes(8192, 4096) > 4096 * 4096 * 8
     # compute units the panel chain of an n x n factorisation has to be resident on (one workgroup per 64 rows below
