@@ -395,12 +395,11 @@ def test_qr_factor_triangular_tile_size():
     np.testing.assert_allclose(r, ro, atol=1e-10)
 
 
-@pytest.mark.parametrize("log_cond", [6, 12])
-def test_chol_trsm_ill_conditioned(log_cond):
-    """explicit inverses of 128 / 512-wide diagonal blocks must not cost backward stability"""
+@pytest.mark.parametrize("log_cond,n", [(6, 1024), (12, 1024), (10, 2048)])
+def test_chol_trsm_ill_conditioned(log_cond, n):
+    """explicit inverses of 128 / 512 / 1024-wide diagonal blocks must not cost backward stability"""
     import scipy.linalg as sl
     rng = np.random.default_rng(log_cond)
-    n = 1024
     Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
     A = (Q * np.logspace(0, -log_cond, n)) @ Q.T
     A = (A + A.T) / 2
@@ -577,3 +576,30 @@ def test_trailing_updates_of_a_block_column_run_batched(hbm_store):
     ref = oracle.cholesky(A, b)
     np.testing.assert_allclose(L, ref, rtol=1e-10, atol=1e-10 * np.abs(ref).max())
     program.free()
+
+
+@pytest.mark.parametrize("n,m", [(1024, 192), (1536, 64), (640, 130)])
+def test_trsm_in_place_through_the_abi(n, m):
+    """npw_dtrsm_rltn_inv with X == B (allowed by the header): the first column block is solved in place with the
+    128-wide block inverses, the rest with the wide inverse groups; same answer as the out-of-place call."""
+    import ctypes
+    from numpywren_amd import _ffi
+    be = kernels.get_backend()
+    lib = be.lib
+    rng = np.random.default_rng(n + m)
+    G = rng.standard_normal((n, n))
+    Lh = np.linalg.cholesky(G @ G.T + n * np.eye(n))
+    Bh = rng.standard_normal((m, n))
+    L, B = be.to_device(Lh), be.to_device(Bh)
+    winv = be.alloc(lib.npw_dtrtri_diag_bytes(n))
+    ws = be.alloc(lib.npw_dtrsm_rltn_inv_workspace_bytes(m, n))
+    sh = be.default_stream.handle
+    _ffi.check(lib.npw_dtrtri_diag(n, L.ptr, n, winv.ptr, sh), "trtri_diag")
+    X = be.empty((m, n))
+    _ffi.check(lib.npw_dtrsm_rltn_inv(m, n, L.ptr, n, winv.ptr, B.ptr, n, X.ptr, n, ws.ptr, sh), "trsm")
+    _ffi.check(lib.npw_dtrsm_rltn_inv(m, n, L.ptr, n, winv.ptr, B.ptr, n, B.ptr, n, ws.ptr, sh), "trsm in place")
+    be.synchronize()
+    out, inplace = be.to_host(X), be.to_host(B)
+    ref = oracle.trsm(Lh, Bh)
+    np.testing.assert_allclose(out, ref, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(inplace, ref, rtol=1e-9, atol=1e-10)
