@@ -155,26 +155,29 @@ int npw_dtrsm_rltn(int64_t m, int64_t n, const double* L, int64_t ldl, const dou
  * the same L (reference numpywren/algs.py:243-246: O[j,i] = trsm(O[i,i], S[i,j,i]) for all j),
  * invert its diagonal blocks once:
  *   npw_dtrtri_diag      Winv <- inverses of the diagonal blocks of the n x n lower triangular L
- *                        (the 512 x 512 diagonal blocks; 128 x 128 ones in a ragged tail).  The
+ *                        (1024 x 1024 diagonal groups, 512 / 128 wide ones next to a ragged end).  The
  *                        layout is private to the library: callers only size it with
  *                        npw_dtrtri_diag_bytes(n) and hand it to npw_dtrsm_rltn_inv.
  *   npw_dtrsm_rltn_inv   X = B * L^-T using those inverses; workspace:
- *                        npw_dtrsm_rltn_inv_workspace_bytes(m, n) bytes.
+ *                        npw_dtrsm_rltn_inv_workspace_bytes(m, n) bytes.  skip_y: optional device flag (see
+ *                        npw_is_zero): if set, X = 0 exactly -- kernels.trsm's `if np.allclose(y, 0): return zeros`
+ *                        (reference kernels.py:255-256) without a launch of its own.
  * npw_dpotrf_lower leaves exactly such a Winv in the first npw_dtrtri_diag_bytes(n) bytes of
  * its workspace, so a factor and its block inverses can be handed on together.            */
 size_t npw_dtrtri_diag_bytes(int64_t n);
 int npw_dtrtri_diag(int64_t n, const double* L, int64_t ldl, double* Winv, npw_stream_t stream);
 size_t npw_dtrsm_rltn_inv_workspace_bytes(int64_t m, int64_t n);
 int npw_dtrsm_rltn_inv(int64_t m, int64_t n, const double* L, int64_t ldl, const double* Winv,
-                       const double* B, int64_t ldb, double* X, int64_t ldx, void* workspace,
-                       npw_stream_t stream);
+                       const double* B, int64_t ldb, double* X, int64_t ldx, const int32_t* skip_y,
+                       void* workspace, npw_stream_t stream);
 /* The same solve for `count` (<= 16) right-hand sides that share L -- the trsm tasks of one block column of the Cholesky
  * DAG (reference algs.py:236-249, statements 1 and 4: O[j, i] = trsm(O[i, i], S[i, j, i]) for every j > i) -- as ONE
  * sequence of batched launches: B[z], X[z] are m x n tiles in separate allocations (16-byte aligned, never aliased);
- * workspace: count * npw_dtrsm_rltn_inv_workspace_bytes(m, n).  Same numbers as count separate calls.             */
+ * workspace: count * npw_dtrsm_rltn_inv_workspace_bytes(m, n); skip_y: `count` flags or NULL.  Same numbers as count
+ * separate calls.                                                                                                     */
 int npw_dtrsm_rltn_inv_batched(int count, int64_t m, int64_t n, const double* L, int64_t ldl, const double* Winv,
-                               const double* const* B, int64_t ldb, double* const* X, int64_t ldx, void* workspace,
-                               npw_stream_t stream);
+                               const double* const* B, int64_t ldb, double* const* X, int64_t ldx,
+                               const int32_t* const* skip_y, void* workspace, npw_stream_t stream);
 
 /* Cholesky factor of the n x n SPD matrix A (only its lower triangle is read):
  * Lout = lower triangular L with A = L L^T, strictly-upper part of Lout set to 0.
@@ -259,6 +262,12 @@ int npw_add_diag(double* A, int64_t rows, int64_t cols, int64_t lda, double lamb
  * (reference numpywren/lambdapack.py:311).                                     */
 int npw_is_zero(const double* A, int64_t rows, int64_t cols, int64_t lda, double atol,
                 int32_t* flag_dev, npw_stream_t stream);
+
+/* The same test for `count` (<= 16) tiles of one shape in ONE launch: flags_dev[z] for tile A[z].  The flags must be
+ * NON-ZERO on entry (the caller presets a pool of them once, e.g. npw_memset_async(flags, 1, bytes)); the kernel only
+ * ever clears one.  Any non-zero value reads as "all close to zero" in every consumer of a flag. */
+int npw_is_zero_batched(int count, const double* const* A, int64_t rows, int64_t cols, int64_t lda, double atol,
+                        int32_t* flags_dev, npw_stream_t stream);
 
 /* A[:] = 0 iff *flag_dev != 0 (device-side select, no host round trip): implements
  * kernels.trsm's `if np.allclose(y, 0): return np.zeros(...)` (reference

@@ -70,8 +70,8 @@ PROTOTYPES = {
     "npw_dtrtri_diag_bytes": (_sz, [_i64]),
     "npw_dtrtri_diag": (c_int, [_i64, _vp, _i64, _vp, _vp]),
     "npw_dtrsm_rltn_inv_workspace_bytes": (_sz, [_i64, _i64]),
-    "npw_dtrsm_rltn_inv": (c_int, [_i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
-    "npw_dtrsm_rltn_inv_batched": (c_int, [c_int, _i64, _i64, _vp, _i64, _vp, POINTER(_vp), _i64, POINTER(_vp), _i64, _vp, _vp]),
+    "npw_dtrsm_rltn_inv": (c_int, [_i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "npw_dtrsm_rltn_inv_batched": (c_int, [c_int, _i64, _i64, _vp, _i64, _vp, POINTER(_vp), _i64, POINTER(_vp), _i64, _vp, _vp, _vp]),
     "npw_dpotrf_lower_workspace_bytes": (_sz, [_i64]),
     "npw_dpotrf_lower": (c_int, [_i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "npw_dpotrf_lower_resident_cus": (c_int, [_i64]),
@@ -88,6 +88,7 @@ PROTOTYPES = {
     "npw_add_n": (c_int, [c_int, POINTER(_vp), POINTER(_i64), POINTER(c_int32), _i64, _i64, _vp, _i64, _vp]),
     "npw_add_diag": (c_int, [_vp, _i64, _i64, _i64, c_double, _vp]),
     "npw_is_zero": (c_int, [_vp, _i64, _i64, _i64, c_double, _vp, _vp]),
+    "npw_is_zero_batched": (c_int, [c_int, _vp, _i64, _i64, _i64, c_double, _vp, _vp]),
     "npw_zero_if": (c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "npw_daxpby": (c_int, [_i64, _i64, c_double, _vp, _i64, c_double, _vp, _i64, _vp, _i64, _vp]),
     "npw_dtranspose": (c_int, [_i64, _i64, _vp, _i64, _vp, _i64, _vp]),

@@ -112,6 +112,34 @@ __global__ void is_zero_kernel(const double* A, int64_t rows, int64_t cols, int6
     }
 }
 
+struct ZeroBatch {
+    const double* A[16];
+};
+
+// the same sweep for up to 16 tiles of one shape in one launch (blockIdx.z = tile); flags[z] must be non-zero on entry
+__global__ void is_zero_batched_kernel(ZeroBatch b, int64_t rows, int64_t cols, int64_t lda, double atol, int32_t* flags) {
+    constexpr int RB = 4;
+    const double* A = b.A[blockIdx.z];
+    int32_t* flag = flags + blockIdx.z;
+    for (int64_t r0 = (int64_t)blockIdx.y * RB; r0 < rows; r0 += (int64_t)gridDim.y * RB) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+        bool bad = false;
+        for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += (int64_t)gridDim.x * blockDim.x) {
+            double v[RB];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) v[i] = (r0 + i < rows) ? A[(r0 + i) * lda + c] : 0.0;
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+                if (!(fabs(v[i]) <= atol)) bad = true;
+        }
+        if (__syncthreads_or(bad)) {
+            if (threadIdx.x == 0 && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
+}
+
 __global__ void zero_if_kernel(double* A, int64_t rows, int64_t cols, int64_t lda, const int32_t* flag) {
     if (*flag == 0) return;
     NPW_FOR_2D(r, c, rows, cols) {
@@ -296,6 +324,25 @@ int npw_is_zero(const double* A, int64_t rows, int64_t cols, int64_t lda, double
     dim3 grid = grid2d(rows, cols);
     if (grid.y > 32) grid.y = 32;
     hipLaunchKernelGGL(is_zero_kernel, grid, dim3(kThreads), 0, s, A, rows, cols, lda, atol, flag_dev);
+    NPW_LAUNCH_CHECK();
+    return NPW_OK;
+}
+
+int npw_is_zero_batched(int count, const double* const* A, int64_t rows, int64_t cols, int64_t lda, double atol,
+                        int32_t* flags_dev, npw_stream_t stream) {
+    NPW_REQUIRE(count >= 0 && count <= 16, "npw_is_zero_batched: 0 .. 16 tiles per call");
+    NPW_REQUIRE(rows >= 0 && cols >= 0, "npw_is_zero_batched: bad sizes");
+    if (count == 0 || rows * cols == 0) return NPW_OK;   // (empty tiles: the preset flags already say "all zero")
+    NPW_REQUIRE(A != nullptr && flags_dev != nullptr && lda >= cols, "npw_is_zero_batched: bad arguments");
+    ZeroBatch b;
+    for (int z = 0; z < 16; ++z) {
+        b.A[z] = A[z < count ? z : 0];
+        NPW_REQUIRE(b.A[z] != nullptr, "npw_is_zero_batched: NULL tile");
+    }
+    dim3 grid = grid2d(rows, cols);
+    if (grid.y > 32) grid.y = 32;
+    grid.z = (unsigned)count;
+    hipLaunchKernelGGL(is_zero_batched_kernel, grid, dim3(kThreads), 0, as_stream(stream), b, rows, cols, lda, atol, flags_dev);
     NPW_LAUNCH_CHECK();
     return NPW_OK;
 }

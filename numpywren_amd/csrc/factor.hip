@@ -1250,12 +1250,18 @@ struct TrsmCtx {
     const int64_t* dB = nullptr;
     const int64_t* dX = nullptr;
     const int64_t* dT = nullptr;
+    // optional device flag (per problem: skip + dskip[z] int32 further): set => the right-hand side counts as zero and
+    // every product of the solve is skipped, which leaves X = 0 exactly (kernels.trsm's allclose(y, 0) short-circuit)
+    const int32_t* skip = nullptr;
+    const int64_t* dskip = nullptr;
 };
 
 // batch options of one GEMM of the recursion: which of B / X / T each operand walks over (L and Winv are shared)
 inline GemmOpts trsm_batch(const TrsmCtx& c, const int64_t* da, const int64_t* dc, const int64_t* dd) {
     GemmOpts o;
+    o.skip0 = c.skip;
     if (c.count > 1) {
+        o.delta_skip0 = c.skip ? c.dskip : nullptr;
         o.batch = c.count;
         o.delta_a = da;
         o.delta_c = dc;
@@ -1482,7 +1488,7 @@ size_t npw_dtrsm_rltn_inv_workspace_bytes(int64_t m, int64_t n) {
 }
 
 int npw_dtrsm_rltn_inv(int64_t m, int64_t n, const double* L, int64_t ldl, const double* Winv, const double* B,
-                       int64_t ldb, double* X, int64_t ldx, void* workspace, npw_stream_t stream) {
+                       int64_t ldb, double* X, int64_t ldx, const int32_t* skip_y, void* workspace, npw_stream_t stream) {
     NPW_REQUIRE(m >= 0 && n >= 0, "npw_dtrsm_rltn_inv: negative dimension");
     if (m == 0 || n == 0) return NPW_OK;
     NPW_REQUIRE(L && Winv && B && X && workspace, "npw_dtrsm_rltn_inv: NULL argument");
@@ -1496,20 +1502,26 @@ int npw_dtrsm_rltn_inv(int64_t m, int64_t n, const double* L, int64_t ldl, const
     }
     TrsmCtx c{m, L, ldl, B, ldb, X, ldx, static_cast<double*>(workspace), n, Winv, 0, as_stream(stream)};
     c.groups_ready = true;  // Winv comes from npw_dtrtri_diag or npw_dpotrf_lower, which both complete the groups
+    c.skip = skip_y;
     return trsm_rec(c, 0, n, false);
 }
 
 int npw_dtrsm_rltn_inv_batched(int count, int64_t m, int64_t n, const double* L, int64_t ldl, const double* Winv,
-                               const double* const* B, int64_t ldb, double* const* X, int64_t ldx, void* workspace,
-                               npw_stream_t stream) {
+                               const double* const* B, int64_t ldb, double* const* X, int64_t ldx,
+                               const int32_t* const* skip_y, void* workspace, npw_stream_t stream) {
     NPW_REQUIRE(count >= 0 && m >= 0 && n >= 0, "npw_dtrsm_rltn_inv_batched: negative argument");
     if (count == 0 || m == 0 || n == 0) return NPW_OK;
     NPW_REQUIRE(count <= 16, "npw_dtrsm_rltn_inv_batched: at most 16 right-hand sides per call");
     NPW_REQUIRE(L && Winv && B && X && workspace, "npw_dtrsm_rltn_inv_batched: NULL argument");
     NPW_REQUIRE(ldl >= n && ldb >= n && ldx >= n, "npw_dtrsm_rltn_inv_batched: leading dimension too small");
     NPW_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "npw_dtrsm_rltn_inv_batched: workspace not 16B aligned");
-    int64_t dB[16], dX[16], dT[16];
+    int64_t dB[16], dX[16], dT[16], dS[16];
     for (int z = 0; z < count; ++z) {
+        dS[z] = 0;
+        if (skip_y) {
+            NPW_REQUIRE(skip_y[z] != nullptr, "npw_dtrsm_rltn_inv_batched: NULL skip flag (problem %d)", z);
+            dS[z] = skip_y[z] - skip_y[0];
+        }
         NPW_REQUIRE(B[z] && X[z] && (const void*)B[z] != (const void*)X[z], "npw_dtrsm_rltn_inv_batched: B[%d] / X[%d] NULL or aliased", z, z);
         NPW_REQUIRE(((reinterpret_cast<uintptr_t>(B[z]) | reinterpret_cast<uintptr_t>(X[z])) & 15) == 0,
                     "npw_dtrsm_rltn_inv_batched: tiles must be 16-byte aligned");
@@ -1523,6 +1535,10 @@ int npw_dtrsm_rltn_inv_batched(int count, int64_t m, int64_t n, const double* L,
     c.dB = dB;
     c.dX = dX;
     c.dT = dT;
+    if (skip_y) {
+        c.skip = skip_y[0];
+        c.dskip = dS;
+    }
     return trsm_rec(c, 0, n, false);
 }
 
@@ -1540,7 +1556,7 @@ int npw_dtrsm_rltn(int64_t m, int64_t n, const double* L, int64_t ldl, const dou
     double* Winv = static_cast<double*>(workspace);
     int rc = npw_dtrtri_diag(n, L, ldl, Winv, stream);
     if (rc) return rc;
-    return npw_dtrsm_rltn_inv(m, n, L, ldl, Winv, B, ldb, X, ldx, static_cast<char*>(workspace) + winv_bytes(n), stream);
+    return npw_dtrsm_rltn_inv(m, n, L, ldl, Winv, B, ldb, X, ldx, nullptr, static_cast<char*>(workspace) + winv_bytes(n), stream);
 }
 
 int npw_dpotrf_lower_resident_cus(int64_t n) { return n <= 0 ? 0 : (int)potrf_resident_wgs(n); }

@@ -71,6 +71,19 @@ class DeviceBuffer(object):
                 pass
 
 
+class _FlagSlot(object):
+    """One int32 of a preset flag pool buffer (HipBackend._take_flags); keeps the buffer alive and shares its stream set."""
+    __slots__ = ("ptr", "_pool")
+
+    def __init__(self, pool, ptr):
+        self._pool = pool
+        self.ptr = ptr
+
+    @property
+    def streams(self):
+        return self._pool.streams
+
+
 class PinnedBuffer(object):
     """Page-locked host memory from the backend's pinned pool (hipHostMalloc): the target of asynchronous D2H
     copies when a tile is spilled out of HBM.  `streams` are the copy streams that touched the memory: the buffer is
@@ -719,23 +732,60 @@ class HipBackend(object):
         self._produced(sh, out)
         return out
 
+    def _take_flags(self, k):
+        """k contiguous device int32 flags that read "set" (non-zero): slots of a pool buffer that was preset once --
+        a flag costs no launch of its own to initialise."""
+        with self._lock:
+            pool = getattr(self, "_flag_pool", None)
+            if pool is None or pool[1] + k > pool[2]:
+                n = 4096
+                buf = self.alloc(4 * n)
+                fs = self.flag_stream()          # a stream nothing else is queued on: the wait below is immediate
+                buf.streams.add(fs.handle)
+                _ffi.check(self.lib.npw_memset_async(buf.ptr, 1, 4 * n, fs.handle), "preset flags")
+                self.stream_sync(fs)
+                pool = self._flag_pool = [buf, 0, n]
+            first = pool[1]
+            pool[1] += k
+            return [_FlagSlot(pool[0], pool[0].ptr + 4 * (first + i)) for i in range(k)]
+
+    def zero_flags(self, tiles, stream=None, atol=1e-8):
+        """Device int32 flags == np.allclose(tile, 0), one per tile, computed once per tile version and cached with it.
+        Tiles of one shape that still lack a flag share ONE launch (npw_is_zero_batched, <= 16 tiles)."""
+        sh = self._sh(stream)
+        todo, seen = {}, set()
+        for t in tiles:
+            if t.zero_flag is None and id(t) not in seen:
+                seen.add(id(t))
+                t64 = self.as_f64(t, sh)
+                todo.setdefault(t64.rows_cols(), []).append((t, t64))
+        fresh = []
+        for (r, c), group in todo.items():
+            for c0 in range(0, len(group), 16):
+                part = group[c0:c0 + 16]
+                slots = self._take_flags(len(part))
+                self._use(sh, *[t64 for _, t64 in part])
+                slots[0].streams.add(sh)
+                ptrs = (ctypes.c_void_p * len(part))(*[t64.ptr for _, t64 in part])
+                _ffi.check(self.lib.npw_is_zero_batched(len(part), ptrs, r, c, c, atol, slots[0].ptr, sh), "is_zero")
+                for (t, _), slot in zip(part, slots):
+                    t.zero_flag = slot
+                    fresh.append(t)
+        if fresh:
+            # A flag is only ever consumed on streams that also wait for its tile (`_use`), so the tile's event must
+            # cover the flag kernel: ALWAYS a fresh event recorded behind it -- also when it ran on the producer's own
+            # stream, whose earlier event says nothing about the flag (a consumer on another stream would read it
+            # half-computed).
+            ready = _Ready(self.record_new(sh), sh, self)
+            for t in fresh:
+                t.ready = ready
+        return [t.zero_flag for t in tiles]
+
     def zero_flag(self, tile, stream=None, atol=1e-8):
         """Device int32 flag == np.allclose(tile, 0); computed once per tile version and cached."""
         if tile.zero_flag is not None:
             return tile.zero_flag
-        sh = self._sh(stream)
-        t64 = self.as_f64(tile, sh)
-        self._use(sh, t64)
-        flag = self.alloc(4)
-        flag.streams.add(sh)
-        r, c = t64.rows_cols()
-        _ffi.check(self.lib.npw_is_zero(t64.ptr, r, c, c, atol, flag.ptr, sh), "is_zero")
-        # The flag is only ever consumed on streams that also wait for the tile (`_use`), so the tile's event must cover
-        # the flag kernels: ALWAYS a fresh event recorded behind them -- also when they ran on the producer's own stream,
-        # whose earlier event says nothing about the flag (a consumer on another stream would read it half-computed).
-        tile.ready = _Ready(self.record_new(sh), sh, self)
-        tile.zero_flag = flag
-        return flag
+        return self.zero_flags([tile], stream, atol)[0]
 
     def read_flag(self, flag, stream=None):
         sh = self._sh(stream)
@@ -804,8 +854,7 @@ class HipBackend(object):
             raise ValueError(f"syrk: operands could not be broadcast together: s{S.shape} x{X.shape} y{Y.shape}")
         fx = fy = None
         if exact_zero:
-            fx = self.zero_flag(X, sh)
-            fy = fx if Y is X else self.zero_flag(Y, sh)
+            fx, fy = self.zero_flags([X, Y], sh)
         out = S if (inplace and not S.shared) else self.empty((m, n), _F64)
         self._use(sh, S, X, Y, out)
         # X is Y on the diagonal tiles: the library multiplies the strictly-lower 128 x 128 tiles only, each workgroup
@@ -853,8 +902,8 @@ class HipBackend(object):
             n = problems[idxs[0]][2].shape[0]
             fxs = fys = None
             if exact_zero:
-                fxs = [self.zero_flag(problems[i][1], sh) for i in idxs]
-                fys = [self.zero_flag(problems[i][2], sh) for i in idxs]
+                flags = self.zero_flags([problems[i][1] for i in idxs] + [problems[i][2] for i in idxs], sh)
+                fxs, fys = flags[:count], flags[count:]
             res = [self.empty((m, n), _F64) for _ in idxs]
             for i, out in zip(idxs, res):
                 self._use(sh, problems[i][0], problems[i][1], problems[i][2], out)
@@ -916,14 +965,12 @@ class HipBackend(object):
         winv = self._diag_inv(L, n, sh)
         ws = self.alloc(max(16, self.lib.npw_dtrsm_rltn_inv_workspace_bytes(m, n)))
         ws.streams.add(sh)
+        # reference: `if np.allclose(y, 0): return np.zeros(...)` -- the flag makes every product of the solve skip
+        fy = self.zero_flag(Y, sh) if exact_zero else None
         t0 = self._tic("trsm", sh)
-        _ffi.check(self.lib.npw_dtrsm_rltn_inv(m, n, L.ptr, n, winv.ptr, Y.ptr, n, out.ptr, n, ws.ptr, sh), "trsm")
+        _ffi.check(self.lib.npw_dtrsm_rltn_inv(m, n, L.ptr, n, winv.ptr, Y.ptr, n, out.ptr, n, fy.ptr if fy is not None else None,
+                                               ws.ptr, sh), "trsm")
         self._toc("trsm", sh, t0)
-        if exact_zero:
-            # reference: `if np.allclose(y, 0): return np.zeros(...)` -- a device-side select
-            fy = self.zero_flag(Y, sh)
-            fy.streams.add(sh)
-            _ffi.check(self.lib.npw_zero_if(out.ptr, m, n, n, fy.ptr, sh), "zero_if")
         self._produced(sh, out)
         return out
 
@@ -949,14 +996,11 @@ class HipBackend(object):
         ws.streams.add(sh)
         pb = (ctypes.c_void_p * count)(*[y.ptr for y in Ys])
         px = (ctypes.c_void_p * count)(*[x.ptr for x in outs])
+        # reference: `if np.allclose(y, 0): return np.zeros(...)` -- per right-hand side, the flag makes its products skip
+        pf = (ctypes.c_void_p * count)(*[f.ptr for f in self.zero_flags(Ys, sh)]) if exact_zero else None
         t0 = self._tic("trsm_batch", sh)
-        _ffi.check(self.lib.npw_dtrsm_rltn_inv_batched(count, m, n, L.ptr, n, winv.ptr, pb, n, px, n, ws.ptr, sh), "trsm_batched")
+        _ffi.check(self.lib.npw_dtrsm_rltn_inv_batched(count, m, n, L.ptr, n, winv.ptr, pb, n, px, n, pf, ws.ptr, sh), "trsm_batched")
         self._toc("trsm_batch", sh, t0)
-        if exact_zero:
-            for y, x in zip(Ys, outs):   # reference: `if np.allclose(y, 0): return np.zeros(...)` -- a device-side select
-                fy = self.zero_flag(y, sh)
-                fy.streams.add(sh)
-                _ffi.check(self.lib.npw_zero_if(x.ptr, m, n, n, fy.ptr, sh), "zero_if")
         self._produced(sh, *outs)
         return outs
 

@@ -596,8 +596,8 @@ def test_trsm_in_place_through_the_abi(n, m):
     sh = be.default_stream.handle
     _ffi.check(lib.npw_dtrtri_diag(n, L.ptr, n, winv.ptr, sh), "trtri_diag")
     X = be.empty((m, n))
-    _ffi.check(lib.npw_dtrsm_rltn_inv(m, n, L.ptr, n, winv.ptr, B.ptr, n, X.ptr, n, ws.ptr, sh), "trsm")
-    _ffi.check(lib.npw_dtrsm_rltn_inv(m, n, L.ptr, n, winv.ptr, B.ptr, n, B.ptr, n, ws.ptr, sh), "trsm in place")
+    _ffi.check(lib.npw_dtrsm_rltn_inv(m, n, L.ptr, n, winv.ptr, B.ptr, n, X.ptr, n, None, ws.ptr, sh), "trsm")
+    _ffi.check(lib.npw_dtrsm_rltn_inv(m, n, L.ptr, n, winv.ptr, B.ptr, n, B.ptr, n, None, ws.ptr, sh), "trsm in place")
     be.synchronize()
     out, inplace = be.to_host(X), be.to_host(B)
     ref = oracle.trsm(Lh, Bh)
