@@ -136,11 +136,12 @@ int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t l
  * updates of a block column of the Cholesky DAG (one RemoteCall of kernels.syrk each, reference lambdapack.py:360-380)
  * handed over together by the executor.  Arrays of `count` device pointers (16-byte aligned tiles; D[z] may alias
  * S[z]); skip_x / skip_y: arrays of per-problem flags or both NULL.  Every problem is computed exactly as
- * npw_dgemm_nt_sub computes it; X[z] == Y[z] gets no symmetric treatment here. */
+ * npw_dgemm_nt_sub computes it; the symmetric route (X[z] == Y[z]) is taken when ALL problems qualify -- callers batch
+ * diagonal and off-diagonal tiles separately.  workspace: npw_dgemm_nt_sub_workspace_bytes(m, n, k) bytes or NULL. */
 int npw_dgemm_nt_sub_batched(int count, int64_t m, int64_t n, int64_t k, const double* const* S, int64_t lds,
                              const double* const* X, int64_t ldx, const double* const* Y, int64_t ldy,
                              double* const* D, int64_t ldd, const int32_t* const* skip_x,
-                             const int32_t* const* skip_y, npw_stream_t stream);
+                             const int32_t* const* skip_y, void* workspace, npw_stream_t stream);
 
 /* Solve X * L^T = B for X, L lower triangular n x n (non-unit), B and X m x n.
  * Only the lower triangle of L is read.  X may alias B.

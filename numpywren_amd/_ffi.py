@@ -64,7 +64,7 @@ PROTOTYPES = {
                           _i64, _vp, _vp]),
     "npw_dgemm_nt_sub_workspace_bytes": (c_size_t, [_i64, _i64, _i64]),
     "npw_dgemm_nt_sub": (c_int, [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
-    "npw_dgemm_nt_sub_batched": (c_int, [c_int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "npw_dgemm_nt_sub_batched": (c_int, [c_int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "npw_dtrsm_rltn_workspace_bytes": (_sz, [_i64, _i64]),
     "npw_dtrsm_rltn": (c_int, [_i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "npw_dtrtri_diag_bytes": (_sz, [_i64]),

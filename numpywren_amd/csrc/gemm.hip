@@ -831,6 +831,30 @@ bool nt_sub_symmetric(int64_t m, int64_t n, int64_t k, const double* X, int64_t 
 }
 }  // namespace
 
+size_t npw_dgemm_nt_sub_workspace_bytes(int64_t m, int64_t n, int64_t k);
+
+namespace {
+// the m / 128 diagonal 128 x 128 blocks of  D = S - X X^T  (the symmetric route's second launch)
+int nt_sub_diag_blocks(int64_t m, int64_t k, const double* S, int64_t lds, const double* X, int64_t ldx, double* D, int64_t ldd,
+                       const int32_t* skip_x, const int32_t* skip_y, void* workspace, hipStream_t stream) {
+    npw::GemmOpts d;
+    d.skip0 = skip_x;
+    d.skip1 = skip_y;
+    d.batch = (int)(m / 128);
+    d.batch_a = d.batch_b = 128 * ldx;
+    d.batch_c = 128 * (lds + 1);
+    d.batch_d = 128 * (ldd + 1);
+    if (workspace != nullptr && npw_dgemm_nt_sub_workspace_bytes(m, m, k) > 0) {
+        // 128 workgroups with the full k would run alone for 0.18 ms: cut k into chunks (8x the workgroups,
+        // partial products summed in a fixed order)
+        NPW_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "npw_dgemm_nt_sub: workspace not 16B aligned");
+        d.splitk = kDiagSplit;
+        d.splitk_ws = workspace;
+    }
+    return npw::gemm<double>('N', 'T', 128, 128, k, -1.0, X, ldx, X, ldx, 1.0, S, lds, D, ldd, d, stream);
+}
+}  // namespace
+
 size_t npw_dgemm_nt_sub_workspace_bytes(int64_t m, int64_t n, int64_t k) {
     if (m != n || m % 128 != 0 || m < 1024 || k < 1024) return 0;
     return (size_t)(m / 128) * kDiagSplit * 128 * 128 * sizeof(double);
@@ -860,31 +884,19 @@ int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t l
     // their own small batched launch instead (full 128 x 128 blocks).
     int rc = npw::gemm<double>('N', 'T', m, n, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, o, npw::as_stream(stream));
     if (rc) return rc;
-    npw::GemmOpts d;
-    d.skip0 = skip_x;
-    d.skip1 = skip_y;
-    d.batch = (int)(m / 128);
-    d.batch_a = d.batch_b = 128 * ldx;
-    d.batch_c = 128 * (lds + 1);
-    d.batch_d = 128 * (ldd + 1);
-    if (workspace != nullptr && npw_dgemm_nt_sub_workspace_bytes(m, n, k) > 0) {
-        // 128 workgroups with the full k would run alone for 0.18 ms: cut k into chunks (8x the workgroups,
-        // partial products summed in a fixed order)
-        NPW_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "npw_dgemm_nt_sub: workspace not 16B aligned");
-        d.splitk = kDiagSplit;
-        d.splitk_ws = workspace;
-    }
-    return npw::gemm<double>('N', 'T', 128, 128, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, d, npw::as_stream(stream));
+    return nt_sub_diag_blocks(m, k, S, lds, X, ldx, D, ldd, skip_x, skip_y, workspace, npw::as_stream(stream));
 }
 
 // `count` independent trailing updates  D[z] = S[z] - X[z] Y[z]^T  of one shape as ONE launch (blockIdx.z = problem):
 // workgroups flow from one problem's tiles into the next one's, so the chip drains once per batch instead of once per
 // tile (measured: 1.917 -> 1.882 ms per 4096^3 update in launches of 16, profiles/r02_syrk_launch_forms.md).  Each problem is computed exactly as
-// npw_dgemm_nt_sub computes it (same tiles, same order of products).  X[z] == Y[z] (the symmetric form) is not
-// batched: callers issue those tiles one by one.
+// npw_dgemm_nt_sub computes it (same tiles, same order of products).  When EVERY problem has X[z] == Y[z] (and the
+// symmetric route's shape) the batch takes that route: one launch over all problems' strictly-lower tile pairs, then
+// the diagonal blocks problem by problem (workspace: npw_dgemm_nt_sub_workspace_bytes(m, n, k), may be NULL).
 int npw_dgemm_nt_sub_batched(int count, int64_t m, int64_t n, int64_t k, const double* const* S, int64_t lds,
                              const double* const* X, int64_t ldx, const double* const* Y, int64_t ldy, double* const* D,
-                             int64_t ldd, const int32_t* const* skip_x, const int32_t* const* skip_y, npw_stream_t stream) {
+                             int64_t ldd, const int32_t* const* skip_x, const int32_t* const* skip_y, void* workspace,
+                             npw_stream_t stream) {
     NPW_REQUIRE(count >= 0 && m >= 0 && n >= 0 && k >= 0, "npw_dgemm_nt_sub_batched: negative argument");
     if (count == 0 || m == 0 || n == 0) return NPW_OK;
     NPW_REQUIRE(count <= 16, "npw_dgemm_nt_sub_batched: at most 16 problems per call");
@@ -906,8 +918,13 @@ int npw_dgemm_nt_sub_batched(int count, int64_t m, int64_t n, int64_t k, const d
             ds1[z] = skip_y[z] - skip_y[0];
         }
     }
+    // every problem with X[z] == Y[z] and the symmetric route's shape: ONE launch over the strictly-lower tiles of all
+    // problems (each workgroup writes its tile and the mirror tile), then each problem's diagonal blocks
+    bool symmetric = true;
+    for (int z = 0; z < count; ++z) symmetric = symmetric && nt_sub_symmetric(m, n, k, X[z], ldx, Y[z], ldy);
     npw::GemmOpts o;
-    o.tag = 1;
+    o.tag = symmetric ? 2 : 1;
+    if (symmetric) o.lower_only = o.strict_lower = o.force_big = true;
     o.skip0 = skip_x ? skip_x[0] : nullptr;
     o.skip1 = skip_y ? skip_y[0] : nullptr;
     if (count > 1) {
@@ -919,7 +936,14 @@ int npw_dgemm_nt_sub_batched(int count, int64_t m, int64_t n, int64_t k, const d
         o.delta_skip0 = ds0;
         o.delta_skip1 = ds1;
     }
-    return npw::gemm<double>('N', 'T', m, n, k, -1.0, X[0], ldx, Y[0], ldy, 1.0, S[0], lds, D[0], ldd, o, npw::as_stream(stream));
+    int rc = npw::gemm<double>('N', 'T', m, n, k, -1.0, X[0], ldx, Y[0], ldy, 1.0, S[0], lds, D[0], ldd, o, npw::as_stream(stream));
+    if (rc || !symmetric) return rc;
+    for (int z = 0; z < count; ++z) {   // (one workspace: the launches of one stream run one after the other)
+        rc = nt_sub_diag_blocks(m, k, S[z], lds, X[z], ldx, D[z], ldd, skip_x ? skip_x[z] : nullptr, skip_y ? skip_y[z] : nullptr,
+                                workspace, npw::as_stream(stream));
+        if (rc) return rc;
+    }
+    return NPW_OK;
 }
 
 }  // extern "C"

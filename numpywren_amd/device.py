@@ -859,7 +859,7 @@ class HipBackend(object):
         self._use(sh, S, X, Y, out)
         # X is Y on the diagonal tiles: the library multiplies the strictly-lower 128 x 128 tiles only, each workgroup
         # writing both tiles of its pair (the full s - x x^T for any s)
-        tname = "syrk_sym" if (X.ptr == Y.ptr and m == n and m % 128 == 0 and m >= 1024 and k % 16 == 0) else "syrk"
+        tname = "syrk_sym" if self._syrk_symmetric_route(X, Y, m, n, k) else "syrk"
         ws = None
         if X.ptr == Y.ptr:
             nbytes = self.lib.npw_dgemm_nt_sub_workspace_bytes(m, n, k)
@@ -874,49 +874,64 @@ class HipBackend(object):
         self._produced(sh, out)
         return out
 
+    def _syrk_symmetric_route(self, X, Y, m, n, k):
+        """The library's condition for the x-is-y route (npw_dgemm_nt_sub: lower tile pairs + mirror)."""
+        return X.ptr == Y.ptr and m == n and m % 128 == 0 and m >= 1024 and k % 16 == 0
+
     def syrk_batched(self, problems, stream=None, exact_zero=True):
-        """[S - X Y^T for (S, X, Y) in problems] for independent updates of one shape (the ready trailing updates of a
-        block column of the Cholesky DAG) as ONE launch (npw_dgemm_nt_sub_batched): the chip drains once per batch
-        instead of once per tile.  Same numbers as `syrk` on each.  Updates with X is Y (the symmetric path) and
-        anything that does not fit the batch are issued one by one."""
+        """[S - X Y^T for (S, X, Y) in problems] for independent updates (the ready trailing updates of a block column of
+        the Cholesky DAG): updates of one shape go out as ONE launch per <= 16 tiles (npw_dgemm_nt_sub_batched) -- the
+        chip drains once per batch instead of once per tile --, the off-diagonal ones (x is not y) and the diagonal
+        ones (x is y: lower tile pairs + mirror) in batches of their own.  Same numbers as `syrk` on each."""
         sh = self._sh(stream)
         outs = [None] * len(problems)
-        group = []
+        groups = {}
         for i, (S, X, Y) in enumerate(problems):
-            ok = all(t.ndim == 2 and t.dtype == _F64 for t in (S, X, Y)) and X.ptr != Y.ptr
-            if ok and group:
-                S0, X0, Y0 = problems[group[0]]
-                ok = S.shape == S0.shape and X.shape == X0.shape and Y.shape == Y0.shape
-            if ok and X.shape[1] == Y.shape[1] and S.shape == (X.shape[0], Y.shape[0]):
-                group.append(i)
-            else:
+            ok = all(t.ndim == 2 and t.dtype == _F64 for t in (S, X, Y)) and X.shape[1] == Y.shape[1] and \
+                S.shape == (X.shape[0], Y.shape[0])
+            if not ok:
                 outs[i] = self.syrk(S, X, Y, stream, inplace=False, exact_zero=exact_zero)
-        for c0 in range(0, len(group), 16):
-            idxs = group[c0:c0 + 16]
-            if len(idxs) == 1:
-                S, X, Y = problems[idxs[0]]
-                outs[idxs[0]] = self.syrk(S, X, Y, stream, inplace=False, exact_zero=exact_zero)
                 continue
-            count = len(idxs)
-            m, k = problems[idxs[0]][1].shape
-            n = problems[idxs[0]][2].shape[0]
-            fxs = fys = None
-            if exact_zero:
-                flags = self.zero_flags([problems[i][1] for i in idxs] + [problems[i][2] for i in idxs], sh)
-                fxs, fys = flags[:count], flags[count:]
-            res = [self.empty((m, n), _F64) for _ in idxs]
-            for i, out in zip(idxs, res):
-                self._use(sh, problems[i][0], problems[i][1], problems[i][2], out)
-            arr = lambda ptrs: (ctypes.c_void_p * count)(*ptrs)
-            t0 = self._tic("syrk", sh)
-            _ffi.check(self.lib.npw_dgemm_nt_sub_batched(
-                count, m, n, k, arr([problems[i][0].ptr for i in idxs]), n, arr([problems[i][1].ptr for i in idxs]), k,
-                arr([problems[i][2].ptr for i in idxs]), k, arr([o.ptr for o in res]), n,
-                arr([f.ptr for f in fxs]) if fxs else None, arr([f.ptr for f in fys]) if fys else None, sh), "syrk_batched")
-            self._toc("syrk", sh, t0, count)
-            self._produced(sh, *res)
-            for i, out in zip(idxs, res):
-                outs[i] = out
+            m, k = X.shape
+            n = Y.shape[0]
+            sym = self._syrk_symmetric_route(X, Y, m, n, k)
+            if X.ptr == Y.ptr and not sym:      # x is y on a shape without the symmetric route: nothing to share
+                outs[i] = self.syrk(S, X, Y, stream, inplace=False, exact_zero=exact_zero)
+                continue
+            groups.setdefault((m, n, k, sym), []).append(i)
+        for (m, n, k, sym), members in groups.items():
+            for c0 in range(0, len(members), 16):
+                idxs = members[c0:c0 + 16]
+                if len(idxs) == 1:
+                    S, X, Y = problems[idxs[0]]
+                    outs[idxs[0]] = self.syrk(S, X, Y, stream, inplace=False, exact_zero=exact_zero)
+                    continue
+                count = len(idxs)
+                fxs = fys = None
+                if exact_zero:
+                    flags = self.zero_flags([problems[i][1] for i in idxs] + [problems[i][2] for i in idxs], sh)
+                    fxs, fys = flags[:count], flags[count:]
+                res = [self.empty((m, n), _F64) for _ in idxs]
+                for i, out in zip(idxs, res):
+                    self._use(sh, problems[i][0], problems[i][1], problems[i][2], out)
+                ws = None
+                if sym:
+                    nbytes = self.lib.npw_dgemm_nt_sub_workspace_bytes(m, n, k)
+                    if nbytes:
+                        ws = self.alloc(nbytes)
+                        ws.streams.add(sh)
+                arr = lambda ptrs: (ctypes.c_void_p * count)(*ptrs)
+                tname = "syrk_sym" if sym else "syrk"
+                t0 = self._tic(tname, sh)
+                _ffi.check(self.lib.npw_dgemm_nt_sub_batched(
+                    count, m, n, k, arr([problems[i][0].ptr for i in idxs]), n, arr([problems[i][1].ptr for i in idxs]), k,
+                    arr([problems[i][2].ptr for i in idxs]), k, arr([o.ptr for o in res]), n,
+                    arr([f.ptr for f in fxs]) if fxs else None, arr([f.ptr for f in fys]) if fys else None,
+                    ws.ptr if ws is not None else None, sh), "syrk_batched")
+                self._toc(tname, sh, t0, count)
+                self._produced(sh, *res)
+                for i, out in zip(idxs, res):
+                    outs[i] = out
         return outs
 
     def _diag_inv(self, L, n, sh):

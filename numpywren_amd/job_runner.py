@@ -170,30 +170,29 @@ class LambdaPackExecutor(object):
                 return []
         except Exception:
             return []
-        # fill the window (weight 1.0) without running past it: the full chip waits for BOTH partitions.  Whole-window
-        # tasks first; lighter ones (a symmetric update: 0.69) only when no such task is ready.
-
+        # Fill the window (weight 1.0: the factorisation on its 64 CUs takes as long as one off-diagonal update on the
+        # other 192) without running far past it -- the full chip waits for BOTH partitions.  Best: one whole-window
+        # update (2.85 ms beside a 2.85 ms chol); then two light ones (x is y: 0.69 each) sharing one batched launch
+        # (measured 3.2 ms for the pair there); then a single light one.
         def weigh(e2, v2):
             w = getattr(self.compiled.kernel(e2), "_npw_chain_weight", None)
             return None if w is None else w(self.compiled.task(e2, v2))
 
-        def pred_full(e2, v2):
+        def light(e2, v2):
+            w = weigh(e2, v2)
+            return w is not None and w < 0.95
+
+        def full(e2, v2):
             w = weigh(e2, v2)
             return w is not None and w >= 0.95
 
-        picked = self.program.dequeue_matching(pred_full, 1)
+        picked = self.program.dequeue_matching(full, 1)
         if picked:
             return picked
-        total = [0.0]
-
-        def pred_light(e2, v2):
-            w = weigh(e2, v2)
-            if w is None or total[0] + w > 1.05:
-                return False
-            total[0] += w
-            return True
-
-        return self.program.dequeue_matching(pred_light, 8)
+        pair = self.program.dequeue_matching(light, 2) if self.batch_tasks > 1 else []
+        if len(pair) == 2 and not (pair[0][0] == pair[1][0] and self.batch_fn(pair[0][0]) is not None):
+            self.program._enqueue(pair.pop())
+        return pair or self.program.dequeue_matching(light, 1)
 
     def is_chain_task(self, expr_idx):
         return self.chain_cus > 0 and getattr(self.compiled.kernel(expr_idx), "_npw_chain_resident_cus", None) is not None
@@ -215,8 +214,11 @@ class LambdaPackExecutor(object):
         be.wait_event(rest, ev)
         be.recycle_event(ev)
         out = [self.run_task(node[0], node[1], stream=chain)]
-        for e, v in companions:
-            out.append(self.run_task(e, v, stream=rest))
+        if len(companions) > 1 and self.batch_fn(companions[0][0]) is not None and all(c[0] == companions[0][0] for c in companions):
+            out.append(self.run_batch(companions, stream=rest))
+        else:
+            for e, v in companions:
+                out.append(self.run_task(e, v, stream=rest))
         for part in (chain, rest):
             ev = be.record_new(part)
             be.wait_event(full, ev)
@@ -304,14 +306,15 @@ class LambdaPackExecutor(object):
             return None
         return getattr(self.compiled.kernel(expr_idx), "_npw_batch", None)
 
-    def run_batch(self, nodes):
+    def run_batch(self, nodes, stream=None):
         """Run the ready tasks `nodes` (all of the same expr_idx, whose kernel has a `_npw_batch`) with one call.
         Same reads, writes and bookkeeping as run_task for each of them."""
         t_enq = time.time()
         expr_idx = nodes[0][0]
         compute = self.compiled.kernel(expr_idx)
         mats = self.compiled.matrices
-        stream = self.pick_stream(compute)
+        if stream is None:
+            stream = self.pick_stream(compute)
         tasks = [self.compiled.task(e, v) for e, v in nodes]
         arg_lists, kwargs_list, read_bytes = [], [], 0
         for task in tasks:

@@ -536,8 +536,28 @@ def test_syrk_batched_equals_one_by_one(m, n, k, count):
     del junk
 
 
-def test_syrk_batched_mixed_kinds_fall_back_one_by_one():
-    """x is y (the symmetric path), another shape and fp32 operands are issued one by one inside syrk_batched."""
+def test_syrk_batched_symmetric_route_equals_one_by_one():
+    """Several x-is-y updates of one shape in one batch (strictly-lower tile pairs of all problems in ONE launch, then the
+    diagonal blocks): bit for bit `syrk` on each, one of them with an all-zero x (short-circuit: s comes back)."""
+    be = kernels.get_backend()
+    rng = np.random.default_rng(12)
+    n, k, count = 1024, 384, 3
+    probs = [(rng.standard_normal((n, n)), rng.standard_normal((n, k))) for _ in range(count)]
+    probs[2] = (probs[2][0], np.zeros((n, k)))
+    tiles = []
+    for S, X in probs:
+        dX = be.to_device(X)
+        tiles.append((be.to_device(S), dX, dX))
+    got = be.syrk_batched(tiles)
+    for (S, X), t, d in zip(probs, tiles, got):
+        one = be.to_host(be.syrk(*t))
+        assert np.array_equal(be.to_host(d), one)
+        np.testing.assert_allclose(one, oracle.syrk(S, X, X), rtol=0, atol=1e-12 * k)
+    assert np.array_equal(be.to_host(got[2]), probs[2][0])
+
+
+def test_syrk_batched_mixed_kinds():
+    """x is y (the symmetric route), another shape and a general update in one call: grouped by kind, same answers."""
     be = kernels.get_backend()
     rng = np.random.default_rng(3)
     S = rng.standard_normal((1024, 1024)); X = rng.standard_normal((1024, 256)); Y = rng.standard_normal((1024, 256))
