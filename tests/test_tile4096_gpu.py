@@ -294,3 +294,33 @@ def test_chol_8192_lookahead_limits():
     X = be.trsm(L, Y)
     Rt = be.gemm(X, L, False, True, alpha=1.0, beta=-1.0, C=Y)
     assert np.sqrt(be.sumsq(Rt) / be.sumsq(Y)) < 1e-13
+
+
+def test_batched_launch_forms_4096_equal_single_launches():
+    """The launch forms the executor uses at the real tile size -- several trailing updates per launch (x is not y and
+    x is y), several right-hand sides per solve -- against the single launches, bit for bit (same tiles, same order of
+    products), all on device (sum of squares of the difference)."""
+    be = get_backend()
+    S = [be.fill_random((B, B), 100 + i) for i in range(3)]
+    X = [be.fill_random((B, B), 200 + i) for i in range(3)]
+    Y = [be.fill_random((B, B), 300 + i) for i in range(3)]
+
+    def same(a, b):
+        return be.sumsq(be.axpby(1.0, a, -1.0, b)) == 0.0
+
+    gen = be.syrk_batched([(S[i], X[i], Y[i]) for i in range(3)])
+    for i in range(3):
+        assert same(gen[i], be.syrk(S[i], X[i], Y[i]))
+    sym = be.syrk_batched([(S[i], X[i], X[i]) for i in range(3)])
+    for i in range(3):
+        one = be.syrk(S[i], X[i], X[i])
+        assert same(sym[i], one)
+        # and the x-is-y route equals the general kernel on (x, copy of x) up to the summation order of the diagonal blocks
+        full = be.syrk(S[i], X[i], be.copy(X[i]))
+        assert be.sumsq(be.axpby(1.0, one, -1.0, full)) <= (1e-12 * B) ** 2 * B * B
+    G = be.fill_random((B, 256), seed=5)
+    L, info = be.chol(be.add_diag(be.gemm(G, G, False, True), float(B)))
+    assert be.read_flag(info) == 0
+    solved = be.trsm_batched(L, Y)
+    for i in range(3):
+        assert same(solved[i], be.trsm(L, Y[i]))
