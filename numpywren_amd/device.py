@@ -222,7 +222,8 @@ class HipBackend(object):
         self.clock_khz = khz.value
         self._lock = threading.RLock()
         self._free = {}      # nbytes -> [ptr]
-        self._pending = []   # (ptr, nbytes, [event handles])
+        self._pending = []   # ({stream: event}, [(ptr, nbytes, streams)]): released buffers waiting for their last users
+        self._deferred = []  # (ptr, nbytes, streams): released, no event recorded yet (_flush_deferred)
         self._event_pool = []
         self.allocated_bytes = 0
         self.pooled_bytes = 0
@@ -436,7 +437,7 @@ class HipBackend(object):
             if lst:
                 self.pooled_bytes -= nbytes
                 return lst.pop(), nbytes
-            if self._pending:
+            if self._pending or self._deferred:
                 self._drain_pending()
                 lst = self._free.get(nbytes)
                 if lst:
@@ -449,13 +450,13 @@ class HipBackend(object):
             # the same streams -- and (2) hand cached blocks of other sizes back to the driver.
             limit = self.alloc_limit_bytes
             if limit and self.allocated_bytes + nbytes > limit:
-                for idx, (ptr, nb, events) in enumerate(self._pending):
-                    if nb == nbytes:
-                        for e in events:
-                            self.event_sync(e)
-                            self._event_pool.append(e)
-                        del self._pending[idx]
-                        return ptr, nbytes
+                for events, bufs in self._pending:
+                    for idx, (ptr, nb, streams) in enumerate(bufs):
+                        if nb == nbytes:
+                            for sh in streams:
+                                self.event_sync(events[sh])
+                            del bufs[idx]
+                            return ptr, nbytes
                 self._trim_locked()
         over = bool(limit) and self.allocated_bytes + nbytes > limit
         p = ctypes.c_void_p(0)
@@ -480,27 +481,44 @@ class HipBackend(object):
             self.peak_bytes = max(self.peak_bytes, self.allocated_bytes)
         return p.value, nbytes
 
+    def _flush_deferred(self):
+        """One event per stream for ALL buffers released since the last flush (an event record costs ~4 us of stream
+        time on this device: one per released buffer and stream was a third of the idle time between the tasks of a
+        16384^2 Cholesky step).  Recording later than the release is always safe: the event then covers more work."""
+        if not self._deferred:
+            return
+        bufs, self._deferred = self._deferred, []
+        events = {}
+        for _, _, streams in bufs:
+            for sh in streams:
+                if sh not in events:
+                    ev = self.new_event()
+                    _ffi.check(self.lib.npw_event_record(ev, sh))
+                    events[sh] = ev
+        self._pending.append((events, bufs))
+
     def _drain_pending(self):
+        self._flush_deferred()
         still = []
-        for ptr, nbytes, events in self._pending:
-            if all(self.event_done(e) for e in events):
-                for e in events:
-                    self._event_pool.append(e)
-                self._free.setdefault(nbytes, []).append(ptr)
-                self.pooled_bytes += nbytes
+        for events, bufs in self._pending:
+            done = {sh: self.event_done(ev) for sh, ev in events.items()}
+            rest = []
+            for ptr, nbytes, streams in bufs:
+                if all(done[sh] for sh in streams):
+                    self._free.setdefault(nbytes, []).append(ptr)
+                    self.pooled_bytes += nbytes
+                else:
+                    rest.append((ptr, nbytes, streams))
+            if rest:
+                still.append((events, rest))
             else:
-                still.append((ptr, nbytes, events))
+                self._event_pool.extend(events.values())
         self._pending = still
 
     def _release(self, ptr, nbytes, streams):
-        events = []
-        for sh in streams:
-            ev = self.new_event()
-            _ffi.check(self.lib.npw_event_record(ev, sh))
-            events.append(ev)
         with self._lock:
-            if events:
-                self._pending.append((ptr, nbytes, events))
+            if streams:
+                self._deferred.append((ptr, nbytes, tuple(streams)))
             else:
                 self._free.setdefault(nbytes, []).append(ptr)
                 self.pooled_bytes += nbytes
@@ -767,7 +785,9 @@ class HipBackend(object):
                 self._use(sh, *[t64 for _, t64 in part])
                 slots[0].streams.add(sh)
                 ptrs = (ctypes.c_void_p * len(part))(*[t64.ptr for _, t64 in part])
+                t0 = self._tic("is_zero", sh)
                 _ffi.check(self.lib.npw_is_zero_batched(len(part), ptrs, r, c, c, atol, slots[0].ptr, sh), "is_zero")
+                self._toc("is_zero", sh, t0)
                 for (t, _), slot in zip(part, slots):
                     t.zero_flag = slot
                     fresh.append(t)
@@ -953,7 +973,9 @@ class HipBackend(object):
         elif aux.get("diag_inv_complete") is False:
             winv = cached[0]
             winv.streams.add(sh)
+            t0 = self._tic("trtri_complete", sh)
             _ffi.check(self.lib.npw_dtrtri_complete(n, L.ptr, n, winv.ptr, sh), "trtri_complete")
+            self._toc("trtri_complete", sh, t0)
             cached = (winv, (self.record_new(sh), sh))
             aux["diag_inv"] = cached
             aux["diag_inv_complete"] = True
