@@ -1279,20 +1279,16 @@ int trsm_rec(const TrsmCtx& c, int64_t coff, int64_t n, bool touched) {
     const int64_t lds = touched ? c.ldt : c.ldb;
     const int64_t* dsrc = touched ? c.dT : c.dB;
     if (c.groups_ready && !inplace0 && n == LW && col % LW == 0) {
-        // A whole group: X = src * inv(L_group)^T with the group's explicit inverse  W = [W11 0; W21 W22],
-        // W21 = -W22 L21 W11, in two independent products (instead of leaf, update, leaf):
-        //   X_lo = src_lo W11^T,     X_hi = [src_lo src_hi] [W21 W22]^T
-        // the same flops in fewer, longer-k launches; both read `src`, none reads the other's result.
+        // A whole group: X = src * inv(L_group)^T with the group's explicit inverse W = [W11 0; W21 W22],
+        // W21 = -W22 L21 W11 -- ONE product instead of leaf, update, leaf: the same flops (W is lower triangular: column
+        // tile n0 stops at k = n0 + BN) in one launch.  On 64 x 64 tiles: their k limits follow the diagonal twice as
+        // closely as the 128 x 128 tiling's, whose unequal tiles made this form slower than the three launches
+        // (per right-hand side: three launches 1.21 ms, two 1.17, this 1.10).
         const double* Wg = c.Winv + (size_t)(col / LW) * LW * LW;
-        GemmOpts lo = trsm_batch(c, dsrc, nullptr, c.dX);
-        lo.b_lower_tri = true;   // W11 lower triangular: column tile n0 stops at k = n0 + BN
-        int rc = gemm<double>('N', 'T', c.m, HW, HW, 1.0, src, lds, Wg, LW, 0.0, nullptr, 0, c.X + coff, c.ldx, lo, c.s);
-        if (rc) return rc;
-        GemmOpts hi = trsm_batch(c, dsrc, nullptr, c.dX);
-        hi.b_lower_tri = true;   // W22 lower triangular behind the HW columns of W21
-        hi.b_tri_offset = HW;
-        return gemm<double>('N', 'T', c.m, HW, LW, 1.0, src, lds, Wg + (size_t)HW * LW, LW, 0.0, nullptr, 0, c.X + coff + HW, c.ldx,
-                            hi, c.s);
+        GemmOpts g = trsm_batch(c, dsrc, nullptr, c.dX);
+        g.b_lower_tri = true;
+        g.force_small = true;
+        return gemm<double>('N', 'T', c.m, LW, LW, 1.0, src, lds, Wg, LW, 0.0, nullptr, 0, c.X + coff, c.ldx, g, c.s);
     }
     const bool half_leaf = c.groups_ready && !inplace0 && n == HW && col % HW == 0;
     if (n <= NB || half_leaf) {

@@ -775,7 +775,7 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
         const char* e = getenv("NPW_GEMM_BIG_MIN_SHORTK");
         return e ? (int64_t)atoi(e) : (int64_t)512;  // k <= 256: prologue/epilogue-bound, more workgroups win
     }();
-    const bool big = opts.force_big || (wg128 >= (k <= 256 ? big_min_shortk : big_min));
+    const bool big = !opts.force_small && (opts.force_big || (wg128 >= (k <= 256 ? big_min_shortk : big_min)));
     if (big) {
         p.tiles_m = (int)ceil_div(m, 128);
         p.tiles_n = (int)ceil_div(n, 128);

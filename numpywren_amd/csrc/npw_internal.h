@@ -52,6 +52,7 @@ struct GemmOpts {
     int tag = 0;              // 1 = tile-level trailing update (separate kernel symbol for profiling); 2 = its symmetric
                               // form (op(A) op(B) = X X^T, strict_lower): every tile also writes its mirror tile
     bool force_big = false;   // take the 128 x 128 tiling whatever the grid size
+    bool force_small = false; // take the 64 x 64 tiling whatever the grid size (finer k limits for triangular operands)
     int splitk = 1;           // > 1 with splitk_ws: cut k into this many chunks (skinny outputs, long k)
     void* splitk_ws = nullptr;  // splitk * m * n elements of scratch
     int* splitk_keep = nullptr;  // non-NULL: leave the partial products in splitk_ws ([problem][split][m][n], alpha and

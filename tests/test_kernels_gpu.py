@@ -484,9 +484,12 @@ def test_trsm_batched_equals_one_by_one(n, m, count):
     del junk
 
 
-def test_trsm_tasks_of_a_block_column_run_as_one_batch(hbm_store):
-    """The executor issues the trailing updates that enable further trsm tasks first and then runs the block column's
-    trsm tasks as ONE batched solve (kernels.trsm._npw_batch); the factor is what the reference's order gives."""
+def test_trsm_tasks_of_a_block_column_run_as_one_batch(hbm_store, monkeypatch):
+    """The executor issues the trailing updates that enable further trsm tasks first and then hands the block column's
+    trsm tasks to kernels.trsm._npw_batch together, which runs them as ONE batched solve from _TRSM_BATCH_MIN right-hand
+    sides on (8 by default; lowered here so that a 5 x 5 tile grid exercises it); the factor is what the reference's
+    order gives."""
+    monkeypatch.setattr(kernels, "_TRSM_BATCH_MIN", 2)
     from numpywren_amd import alg_wrappers, job_runner
     from numpywren_amd import lambdapack as lp
     from numpywren_amd.matrix import BigMatrix
