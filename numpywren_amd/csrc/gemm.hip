@@ -110,8 +110,7 @@ struct GemmParams {
     int64_t batch_a, batch_b, batch_c, batch_d;  // element strides between the problems of a batch (blockIdx.z)
     int batch_inner;                                  // two-level batch: z -> (z / inner, z % inner)
     int64_t batch2_a, batch2_b, batch2_c, batch2_d;
-    int b_lower_tri;                                  // k range of column tile n0 ends at b_tri_offset + n0 + BN
-    int b_tri_offset;
+    int b_lower_tri;                                  // k range of column tile n0 ends at n0 + BN
     int k_from_diag;                                  // k range of tile (m0, n0) starts at max(m0, n0) (trapezoidal operands)
     int a_upper_tri;                                  // k range of row tile m0 starts at m0 (op(A) upper triangular)
     int use_delta;                                    // irregular batch: element offsets per problem instead of strides
@@ -246,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
     if (p.k_from_diag) kb = max(kb, (max(m0, n0) / BK) * BK);  // V^T V with V lower trapezoidal: rows above are zero
     if (p.a_upper_tri) kb = max(kb, (m0 / BK) * BK);           // T1 * X with T1 upper triangular: columns left of the diagonal are zero
     int kend = p.k_chunk > 0 ? min(p.K, kb + p.k_chunk) : p.K;
-    if (p.b_lower_tri) kend = min(kend, p.b_tri_offset + n0 + BN);  // rows of W^T below the diagonal block are zero
+    if (p.b_lower_tri) kend = min(kend, n0 + BN);  // rows of W^T below the diagonal block are zero
     int nk = (kend - kb + BK - 1) / BK;
     if ((p.skip0 && *p.skip0) || (p.skip1 && *p.skip1)) nk = 0;
 
@@ -715,7 +714,6 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
     p.batch2_c = opts.batch2_c;
     p.batch2_d = opts.batch2_d;
     p.b_lower_tri = opts.b_lower_tri ? 1 : 0;
-    p.b_tri_offset = opts.b_tri_offset;
     p.k_from_diag = opts.k_from_diag ? 1 : 0;
     p.a_upper_tri = opts.a_upper_tri ? 1 : 0;
     p.use_delta = 0;

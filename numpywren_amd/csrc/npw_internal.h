@@ -64,7 +64,6 @@ struct GemmOpts {
     int batch_inner = 0;      // > 0: two-level batch, problem z = (z / inner) * batch_x + (z % inner) * batch2_x
     int64_t batch2_a = 0, batch2_b = 0, batch2_c = 0, batch2_d = 0;
     bool b_lower_tri = false;  // op(B) = W^T with W (n x k) lower triangular: column tile n0 only needs k < n0 + BN
-    int b_tri_offset = 0;      // ... + this offset (W = [W21 W22] with W22 lower triangular: offset = columns of W21)
     bool k_from_diag = false;  // op(A)^T, op(B) (k x m, k x n) lower trapezoidal: tile (m0, n0) only needs k >= max(m0, n0)
     bool a_upper_tri = false;  // op(A) (m x k) upper triangular: row tile m0 only needs k >= m0
     // Irregular batch: problem z's operand is (pointer of problem 0) + delta_x[z] ELEMENTS instead of z * batch_x
