@@ -70,6 +70,51 @@ def _worker(rank, world, port, scenario, outdir):
         assert res["bytes_sent"] > 0 or world == 1
         assert res["headers"] == 0     # every receiver derived shape and dtype from the static plan (TileMetaPlan)
         assert meta["intermediates"][0].block_idxs_exist == []   # reclaim works under sharding
+    elif scenario == "grid16":
+        # the shape of the driver's 8-GPU run (bench.py --gpus 8: 65536^2 in 4096^2 tiles): a 16 x 16 tile grid on the
+        # 2 x 4 process grid, 816 tasks, every panel tile pushed to the owners of its consumers -- with 4 x 4 tiles
+        rng = np.random.default_rng(816)
+        nb, b = 16, 4
+        G = rng.standard_normal((nb * b, nb * b))
+        A = G @ G.T + nb * b * np.eye(nb * b)
+        X = BigMatrix("chol_grid16", shape=A.shape, shard_sizes=(b, b))
+        scatter_owned(X, A, "I")
+        program, meta = alg_wrappers.cholesky(X)
+        program.config["executor"]["reclaim_intermediates"] = True
+        program.start()
+        res = dist.lambdapack_run_distributed(program, comm, pipeline_width=3)
+        assert program.program_status() == lp.PS.SUCCESS, program.exceptions
+        got = dist.gather_matrix(meta["outputs"][0], comm)
+        counts = [None] * world
+        comm.dist.all_gather_object(counts, len(res["executed_messages"]))
+        if rank == 0:
+            np.testing.assert_allclose(got, np.linalg.cholesky(A), rtol=1e-10, atol=1e-10)
+            assert sum(counts) == nb * (nb + 1) * (nb + 2) // 6 == 816
+            assert min(counts) > 0
+        assert res["headers"] == 0 and res["bytes_sent"] > 0
+    elif scenario == "tsqr8":
+        # one leaf per rank: every tree edge crosses ranks (the 3 cross-GPU levels of bench.py --workload tsqr --gpus 8)
+        Xh = ALG["tsqr_64_8/X"]
+        X = BigMatrix("tsqr_in_8", shape=Xh.shape, shard_sizes=(8, 8))
+        comm.ownership = dist.tsqr_ownership(world, 8)
+        scatter_owned(X, Xh, "A")
+        assert len(X.block_idxs_exist) == 1
+        program, meta = alg_wrappers.tsqr(X)
+        program.start()
+        res = dist.lambdapack_run_distributed(program, comm, pipeline_width=2)
+        assert program.program_status() == lp.PS.SUCCESS, program.exceptions
+        counts, sent = [None] * world, [None] * world
+        comm.dist.all_gather_object(counts, len(res["executed_messages"]))
+        comm.dist.all_gather_object(sent, res["bytes_sent"])
+        assert sum(counts) == 15 and sum(sent) == 7 * 8 * 8 * 8     # 8 leaves + 7 nodes; one R factor per tree edge
+        R = meta["outputs"][0]
+        if R.tile_exists(3, 0):
+            np.testing.assert_allclose(R.get_block(3, 0), ALG["tsqr_64_8/R_final"], atol=1e-12)
+            result["has_final"] = True
+        flags = [None] * world
+        comm.dist.all_gather_object(flags, bool(result.get("has_final")))
+        assert sum(flags) == 1
+        comm.ownership = None
     elif scenario == "tsqr":
         Xh = ALG["tsqr_64_8/X"]
         X = BigMatrix("tsqr_in", shape=Xh.shape, shard_sizes=(8, 8))
@@ -171,6 +216,15 @@ def _spawn(world, scenario, tmp_path):
 @pytest.mark.parametrize("tag", ["32_8", "40_8_t2", "24_8_lam"])
 def test_cholesky_sharded(world, tag, tmp_path):
     _spawn(world, f"cholesky:{tag}", tmp_path)
+
+
+def test_cholesky_16x16_tiles_on_8_ranks(tmp_path):
+    _spawn(8, "grid16", tmp_path)
+
+
+def test_tsqr_and_gemm_on_8_ranks(tmp_path):
+    _spawn(8, "tsqr8", tmp_path)
+    _spawn(8, "gemm", tmp_path)
 
 
 def test_tsqr_sharded(tmp_path):
