@@ -33,8 +33,8 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense fp64 matrix peak (vendor spec; 74.6 measured by tools/devcheck)
 TILE = 4096
-SYRK_TRAFFIC_BYTES = 2.65e9    # PMC passes of a separate run (2 x FETCH_SIZE + WRITE_SIZE per launch of the tagged kernel)
-SYRK_TRAFFIC_SOURCE = "profiles/r02_bench_pmc.json (rocprofv3 --pmc, separate passes)"
+SYRK_TRAFFIC_BYTES = 3.78e9    # PMC passes of a separate run (2 x FETCH_SIZE + WRITE_SIZE per one-tile launch of the tagged kernel)
+SYRK_TRAFFIC_SOURCE = "profiles/r02_bench_pmc_final.json (rocprofv3 --pmc, separate passes)"
 
 
 def build_input(be, nb, b, key, rank=0, world=1, owner=None):
@@ -320,7 +320,7 @@ def main():
                                     # HBM-side bytes per launch: PMC passes of ANOTHER run of this command (2 x FETCH_SIZE +
                                     # WRITE_SIZE, profiles/), not measured in this process; only for the 4096^2 tile
                                     "traffic": SYRK_TRAFFIC_BYTES if b == TILE else None,
-                                    "traffic_unit": "B/launch; from " + SYRK_TRAFFIC_SOURCE + ", not this run (algorithmic 5.37e8)",
+                                    "traffic_unit": "B per tile update; from " + SYRK_TRAFFIC_SOURCE + ", not this run (algorithmic 5.37e8)",
                                     "launches": len(syrk), "avg_ms": round(avg_ms, 4),
                                     "algorithmic_flop_per_launch": 2 * b ** 3}
                 # launches of the same kernel on the 192-CU partition beside a chol on the other 64 (kernel_ms
