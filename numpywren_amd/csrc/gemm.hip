@@ -111,6 +111,8 @@ struct GemmParams {
     int batch_inner;                                  // two-level batch: z -> (z / inner, z % inner)
     int64_t batch2_a, batch2_b, batch2_c, batch2_d;
     int b_lower_tri;                                  // k range of column tile n0 ends at n0 + BN
+    int pad_layout_;                                  // unused; without it the arrays below start 8 bytes earlier and the
+                                                      // 128 x 128 trailing update measures 0.3 % slower (1.9233 vs 1.9176 ms)
     int k_from_diag;                                  // k range of tile (m0, n0) starts at max(m0, n0) (trapezoidal operands)
     int a_upper_tri;                                  // k range of row tile m0 starts at m0 (op(A) upper triangular)
     int use_delta;                                    // irregular batch: element offsets per problem instead of strides
@@ -714,6 +716,7 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
     p.batch2_c = opts.batch2_c;
     p.batch2_d = opts.batch2_d;
     p.b_lower_tri = opts.b_lower_tri ? 1 : 0;
+    p.pad_layout_ = 0;
     p.k_from_diag = opts.k_from_diag ? 1 : 0;
     p.a_upper_tri = opts.a_upper_tri ? 1 : 0;
     p.use_delta = 0;
