@@ -14,7 +14,7 @@ DEFAULTS = {
         # small panel kernel queues ~1 ms behind it and the critical path gets slower, not faster.
         "priority_stream": False,
         "exact_zero_shortcircuit": True,  # reproduce the reference's allclose(x, 0) early-outs
-        "reclaim_intermediates": False,   # free intermediate tiles after their last reader
+        "reclaim_intermediates": False,   # free tiles of non-input / non-output matrices after their last reader (at once if nobody reads them)
         # Ready tasks of one latency-bound kind (qr_factor: the TSQR leaves, the nodes of a tree level) that are
         # handed to the device as a single batched launch sequence; 1 = one task at a time.  32 = what the QR panel kernel
         # holds at once for 4096-row tiles (2 workgroups per CU x 256 CUs / 16 slabs); 128-leaf TSQR: 1046 ms with 16,

@@ -89,6 +89,7 @@ class LambdaPackExecutor(object):
         self._rr = 0
         self.compiled = program.program
         self._readers_left = None
+        self._unread = set()
         # chain partition (one in-order stream only): see run_chain
         self.chain_cus = int(cfg.get("chain_cus", 0) or 0) if n == 1 and self.prio_stream is None else 0
         if self.chain_cus and not (hasattr(self.be, "chain_streams") and 0 < self.chain_cus < getattr(self.be, "compute_units", 0)):
@@ -109,10 +110,16 @@ class LambdaPackExecutor(object):
         self._rr += 1
         return s
 
-    # ---- reclaim bookkeeping: tiles of non-input / non-output matrices die after their last reader ----
+    # ---- reclaim bookkeeping: tiles of non-input / non-output matrices die after their last reader; a tile of such a
+    #      matrix that NO task reads (the V and T factors of the TSQR program: only R goes up the tree) dies as soon as it
+    #      has been stored -- with `reclaim_intermediates` the caller has said that only the program's outputs matter ----
     def _init_reclaim(self):
         left = collections.Counter()
         keep = set(self.compiled.inputs) | set(self.compiled.outputs)
+        read_by_anyone = set()
+        for t in self.compiled.tasks:
+            read_by_anyone.update(t.reads)
+        self._unread = {w for t in self.compiled.tasks for w in t.writes if w[0] not in keep and w not in read_by_anyone}
         for t in self.compiled.tasks:
             local = self.is_local is None or self.is_local(t)
             if local:
@@ -149,6 +156,9 @@ class LambdaPackExecutor(object):
                 self._readers_left[r] -= 1
                 if self._readers_left[r] == 0:
                     self.compiled.matrices[r[0]].delete_block(*r[1])
+        for w in task.writes:
+            if w in self._unread:
+                self.compiled.matrices[w[0]].delete_block(*w[1])
 
     # ---- the panel chain beside trailing updates ----
     def chain_companions(self, expr_idx, var_values):

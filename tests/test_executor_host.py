@@ -96,6 +96,22 @@ def test_reclaim_intermediates(oracle_backend):
     assert len(X.block_idxs_exist) == 16                           # inputs are never reclaimed
 
 
+def test_reclaim_drops_tiles_nobody_reads_at_once(oracle_backend):
+    """TSQR with reclaim_intermediates: V and T of every node are written and never read (only R goes up the tree), so
+    they are dropped as soon as they are stored; the R factors below the root die after their parent; the result stays."""
+    Xh = ALG["tsqr_64_8/X"]
+    X = BigMatrix("tsqr_reclaim", shape=Xh.shape, shard_sizes=(8, Xh.shape[1]))
+    shard_matrix(X, Xh)
+    program, meta = alg_wrappers.tsqr(X)
+    program.config["executor"]["reclaim_intermediates"] = True
+    run(program)
+    assert program.program_status() == lp.PS.SUCCESS
+    R, V, T = meta["outputs"]
+    assert V.block_idxs_exist == [] and T.block_idxs_exist == []
+    np.testing.assert_allclose(np.abs(R.get_block(3, 0)), np.abs(ALG["tsqr_64_8/R_final"]), atol=1e-12)
+    assert len(X.block_idxs_exist) == 8                            # inputs are never reclaimed
+
+
 @pytest.mark.parametrize("tag,b", [("32_8", 8), ("40_8", 8), ("16_8_f32", 8)])
 def test_gemm(tag, b, oracle_backend):
     A, B, C = ALG[f"gemm_{tag}/A"], ALG[f"gemm_{tag}/B"], ALG[f"gemm_{tag}/C"]
