@@ -164,8 +164,9 @@ def _prebuild(build, count):
 class Runner(object):
     """Times K runs of one alg_wrappers program after W warm-up runs, bracketed by a barrier + device synchronise."""
 
-    def __init__(self, be, comm, streams, priority_stream=False):
+    def __init__(self, be, comm, streams, priority_stream=False, r_only=False):
         self.be, self.comm, self.streams, self.priority_stream = be, comm, streams, priority_stream
+        self.r_only = r_only    # TSQR: drop the V / T factors no task reads as they are stored (executor.drop_unread_outputs)
         self.pending = []   # (program, meta) enqueued on the device, not yet waited for
 
     def settle(self):
@@ -187,6 +188,7 @@ class Runner(object):
         for m in meta["outputs"] + meta["intermediates"]:
             m.free()
         program.config["executor"]["reclaim_intermediates"] = True
+        program.config["executor"]["drop_unread_outputs"] = self.r_only
         program.config["executor"]["priority_stream"] = self.priority_stream
         program.start()
         if self.comm is None:
@@ -262,6 +264,8 @@ def main():
                          "transit must not block the tasks behind it)")
     ap.add_argument("--priority-stream", action="store_true", help="panel kernels on a high-priority stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--r-only", action="store_true", help="tsqr: drop the V / T factors as they are stored, whatever the GPU count")
+    ap.add_argument("--keep-vt", action="store_true", help="tsqr: keep V / T even if they overflow into host DRAM")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 65536^2 single-GPU run of the N = 1 line")
     args = ap.parse_args()
 
@@ -358,15 +362,21 @@ def main():
                                       "pct_peak": round(100 * tf / FP64_MFMA_PEAK_TFLOPS, 2),
                                       "syrk_frac": round(2.0 * b ** 3 / (float(np.mean(t2)) * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if t2 else None,
                                       "syrk_launches": len(t2),
-                                      "residual_tile_1_1": cholesky_residual(be, X2, meta2["outputs"][0], nb2)}
+                                      "residual_all_tiles": cholesky_residual(be, X2, meta2["outputs"][0], nb2, full=True)}
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(b)
     elif args.workload == "tsqr":
         # configs[3]: (leaves * 4096) x 4096 fp64 TSQR; leaves in contiguous chunks per GPU, log2(world) exchanged R factors.
-        # The full 256-leaf input also fits ONE GPU (32 GiB + the R factors: the V / T factors nobody reads are dropped as
-        # they are stored, executor.reclaim_intermediates), so every N runs the same problem: strong scaling.
+        # Every N runs the same problem (strong scaling).  What the reference's wrapper returns is [R, V, T]
+        # (alg_wrappers.py:47); V and T of the 511 nodes are ~290 GB, which fits the HBM of 4 or more GPUs and not of 1 or
+        # 2: there the run is R ONLY (executor.drop_unread_outputs: V / T, which no task reads, are dropped as they are
+        # stored) and the line says so.  --keep-vt / --r-only override.
         leaves = args.leaves or 256
         m = leaves * b
+        # (V + T of the 256 leaves and 255 nodes are 160 GiB on top of 32 GiB of input, the R factors in flight and the
+        #  batched factorisation's workspaces: measured on one 288 GB GPU it overflows into the host tier, 7.9 s per run)
+        r_only = args.r_only or (not args.keep_vt and world < 4)
+        run.r_only = r_only
         if comm is not None:
             from numpywren_amd import dist
             comm.ownership = dist.tsqr_ownership(world, leaves)
@@ -382,8 +392,9 @@ def main():
                 "unit": "TFLOP/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
                 "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                "config": {"workload": f"{m}x{b} fp64 TSQR, {leaves} leaves, alg_wrappers.tsqr ({2 * leaves - 1} tasks)",
-                           "tile": b, "streams": args.streams, "parallelism": par}}
+                "config": {"workload": f"{m}x{b} fp64 TSQR, {leaves} leaves, alg_wrappers.tsqr ({2 * leaves - 1} tasks), "
+                                       + ("R only (V / T dropped on store)" if r_only else "R, V, T kept (the reference's outputs)"),
+                           "r_only": r_only, "tile": b, "streams": args.streams, "parallelism": par}}
     else:
         # configs[4]: 32768^2 fp32 GEMM program (fp32 MFMA products, the reference's fp64 add_matrices tree), strong scaling
         nb = args.tiles or 8

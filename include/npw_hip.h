@@ -53,6 +53,9 @@ int npw_get_device(int* device);
 int npw_device_info(int device, char* name, size_t name_len, size_t* total_mem_bytes,
                     int* compute_units, int* clock_khz);
 int npw_mem_info(size_t* free_bytes, size_t* total_bytes);
+/* "domain:bus:device.function" of the physical device: what tells two ranks that see one device each (per-rank
+ * HIP_VISIBLE_DEVICES) whether they sit on the same GPU -- RCCL refuses two ranks of a communicator on one device */
+int npw_device_pci_bus_id(int device, char* out, size_t out_len);
 
 /* ---- memory: the HBM tile store + pinned host staging ----------------------
  * Replaces the S3 object GET/PUT of BigMatrix (reference numpywren/matrix.py:
@@ -65,9 +68,6 @@ int npw_host_free(void* hptr);
 int npw_memcpy_h2d_async(void* dst, const void* src, size_t bytes, npw_stream_t stream);
 int npw_memcpy_d2h_async(void* dst, const void* src, size_t bytes, npw_stream_t stream);
 int npw_memcpy_d2d_async(void* dst, const void* src, size_t bytes, npw_stream_t stream);
-/* copy between devices of one node (xGMI peer copy) */
-int npw_memcpy_peer_async(void* dst, int dst_device, const void* src, int src_device, size_t bytes,
-                          npw_stream_t stream);
 int npw_memset_async(void* dst, int byte_value, size_t bytes, npw_stream_t stream);
 /* strided 2-D copies (rows x row_bytes) for scatter/gather of ragged tiles */
 int npw_memcpy2d_h2d_async(void* dst, size_t dpitch, const void* src, size_t spitch,
@@ -348,10 +348,13 @@ int npw_dgebd2(int64_t n, double* A, int64_t lda, double* d, double* e, void* wo
  *   npw_bcast_tile      the panel broadcast: root -> members as k grouped sends on k xGMI
  *                       links (one fused launch); on a member, the matching receive into
  *                       `tile`; on other ranks a no-op.
- *   npw_sendrecv_tile   grouped exchange with two peers (the TSQR butterfly of R factors).
- *   npw_allgather_tiles every rank contributes bytes_per_rank and receives world * that.
- *   npw_allreduce_max_f64  small control values (timings, failure flags), device memory.
- *   npw_comm_group_start / _end   bracket several transfers into one launch.             */
+ *   npw_comm_group_start / _end   bracket several transfers into ONE launch whose sends and
+ *                       receives progress side by side on their links: dist.py's prologue
+ *                       (the GEMM program's A / B panel pushes: SUMMA's traffic as one
+ *                       all-to-all-v) and the outputs of one batched group of tasks.  Every
+ *                       rank opens and closes its groups at the same points of the sequence.
+ * (Control values -- timings, failure flags, the collective time limit -- travel over the
+ *  host-side control group, not through this library.)                                  */
 #define NPW_COMM_ID_BYTES 128
 typedef void* npw_comm_t;
 int npw_comm_unique_id(void* id_out, size_t id_bytes);
@@ -364,11 +367,6 @@ int npw_send_tile(npw_comm_t comm, const void* tile, size_t bytes, int dst, npw_
 int npw_recv_tile(npw_comm_t comm, void* tile, size_t bytes, int src, npw_stream_t stream);
 int npw_bcast_tile(npw_comm_t comm, void* tile, size_t bytes, int root, const int* members, int nmembers,
                    npw_stream_t stream);
-int npw_sendrecv_tile(npw_comm_t comm, const void* send, size_t send_bytes, int dst, void* recv,
-                      size_t recv_bytes, int src, npw_stream_t stream);
-int npw_allgather_tiles(npw_comm_t comm, const void* send, void* recv, size_t bytes_per_rank,
-                        npw_stream_t stream);
-int npw_allreduce_max_f64(npw_comm_t comm, double* values, size_t count, npw_stream_t stream);
 
 #ifdef __cplusplus
 }

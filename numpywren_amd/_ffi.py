@@ -40,7 +40,6 @@ PROTOTYPES = {
     "npw_memcpy_h2d_async": (c_int, [_vp, _vp, _sz, _vp]),
     "npw_memcpy_d2h_async": (c_int, [_vp, _vp, _sz, _vp]),
     "npw_memcpy_d2d_async": (c_int, [_vp, _vp, _sz, _vp]),
-    "npw_memcpy_peer_async": (c_int, [_vp, c_int, _vp, c_int, _sz, _vp]),
     "npw_memset_async": (c_int, [_vp, c_int, _sz, _vp]),
     "npw_memcpy2d_h2d_async": (c_int, [_vp, _sz, _vp, _sz, _sz, _sz, _vp]),
     "npw_memcpy2d_d2h_async": (c_int, [_vp, _sz, _vp, _sz, _sz, _sz, _vp]),
@@ -109,9 +108,6 @@ PROTOTYPES = {
     "npw_send_tile": (c_int, [_vp, _vp, _sz, c_int, _vp]),
     "npw_recv_tile": (c_int, [_vp, _vp, _sz, c_int, _vp]),
     "npw_bcast_tile": (c_int, [_vp, _vp, _sz, c_int, POINTER(c_int), c_int, _vp]),
-    "npw_sendrecv_tile": (c_int, [_vp, _vp, _sz, c_int, _vp, _sz, c_int, _vp]),
-    "npw_allgather_tiles": (c_int, [_vp, _vp, _vp, _sz, _vp]),
-    "npw_allreduce_max_f64": (c_int, [_vp, _vp, _sz, _vp]),
 }
 NPW_COMM_ID_BYTES = 128
 

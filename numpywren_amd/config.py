@@ -14,7 +14,10 @@ DEFAULTS = {
         # small panel kernel queues ~1 ms behind it and the critical path gets slower, not faster.
         "priority_stream": False,
         "exact_zero_shortcircuit": True,  # reproduce the reference's allclose(x, 0) early-outs
-        "reclaim_intermediates": False,   # free tiles of non-input / non-output matrices after their last reader (at once if nobody reads them)
+        "reclaim_intermediates": False,   # free tiles of non-input / non-output matrices after their last reader
+        # also drop, as soon as they are stored, tiles of such matrices that NO task reads (TSQR's V / T factors, which
+        # the reference's wrapper returns next to R, alg_wrappers.py:47): an explicit "R only" request, never implied
+        "drop_unread_outputs": False,
         # Ready tasks of one latency-bound kind (qr_factor: the TSQR leaves, the nodes of a tree level) that are
         # handed to the device as a single batched launch sequence; 1 = one task at a time.  32 = what the QR panel kernel
         # holds at once for 4096-row tiles (2 workgroups per CU x 256 CUs / 16 slabs); 128-leaf TSQR: 1046 ms with 16,

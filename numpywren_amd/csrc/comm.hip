@@ -31,9 +31,6 @@ struct Rccl {
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
-    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -64,9 +61,7 @@ int load_rccl() {
     const bool ok = bind(h, "ncclGetUniqueId", r.GetUniqueId) && bind(h, "ncclCommInitRank", r.CommInitRank) &&
                     bind(h, "ncclCommDestroy", r.CommDestroy) && bind(h, "ncclCommAbort", r.CommAbort) &&
                     bind(h, "ncclSend", r.Send) && bind(h, "ncclRecv", r.Recv) && bind(h, "ncclGroupStart", r.GroupStart) &&
-                    bind(h, "ncclGroupEnd", r.GroupEnd) && bind(h, "ncclAllGather", r.AllGather) &&
-                    bind(h, "ncclAllReduce", r.AllReduce) && bind(h, "ncclBroadcast", r.Broadcast) &&
-                    bind(h, "ncclGetErrorString", r.GetErrorString);
+                    bind(h, "ncclGroupEnd", r.GroupEnd) && bind(h, "ncclGetErrorString", r.GetErrorString);
     if (!ok) return set_error(NPW_ERR_UNSUPPORTED, "npw_comm: librccl lacks a required entry point (%s)", dlerror());
     g_rccl = r;
     return NPW_OK;
@@ -221,43 +216,6 @@ int npw_bcast_tile(npw_comm_t comm, void* tile, size_t bytes, int root, const in
             return NPW_OK;
         }
     return NPW_OK;  // not a member: nothing to do
-}
-
-int npw_sendrecv_tile(npw_comm_t comm, const void* send, size_t send_bytes, int dst, void* recv, size_t recv_bytes, int src,
-                      npw_stream_t stream) {
-    NPW_REQUIRE(comm != nullptr, "npw_sendrecv_tile: NULL communicator");
-    Comm* c = as_comm(comm);
-    NPW_REQUIRE((send_bytes == 0 || (send != nullptr && dst >= 0 && dst < c->world)) &&
-                    (recv_bytes == 0 || (recv != nullptr && src >= 0 && src < c->world)),
-                "npw_sendrecv_tile: bad arguments");
-    hipStream_t s = stream ? as_stream(stream) : c->stream;
-    NPW_NCCL_CHECK(g_rccl.GroupStart());
-    ncclResult_t r = ncclSuccess;
-    if (send_bytes) r = g_rccl.Send(send, send_bytes, ncclUint8, dst, c->comm, s);
-    if (r == ncclSuccess && recv_bytes) r = g_rccl.Recv(recv, recv_bytes, ncclUint8, src, c->comm, s);
-    if (r != ncclSuccess) {
-        (void)g_rccl.GroupEnd();
-        return set_error(NPW_ERR_HIP, "npw_sendrecv_tile: %s", g_rccl.GetErrorString(r));
-    }
-    NPW_NCCL_CHECK(g_rccl.GroupEnd());
-    return NPW_OK;
-}
-
-int npw_allgather_tiles(npw_comm_t comm, const void* send, void* recv, size_t bytes_per_rank, npw_stream_t stream) {
-    NPW_REQUIRE(comm != nullptr && (bytes_per_rank == 0 || (send != nullptr && recv != nullptr)),
-                "npw_allgather_tiles: NULL argument");
-    Comm* c = as_comm(comm);
-    if (bytes_per_rank == 0) return NPW_OK;
-    NPW_NCCL_CHECK(g_rccl.AllGather(send, recv, bytes_per_rank, ncclUint8, c->comm, stream ? as_stream(stream) : c->stream));
-    return NPW_OK;
-}
-
-int npw_allreduce_max_f64(npw_comm_t comm, double* values, size_t count, npw_stream_t stream) {
-    NPW_REQUIRE(comm != nullptr && (count == 0 || values != nullptr), "npw_allreduce_max_f64: NULL argument");
-    Comm* c = as_comm(comm);
-    if (count == 0) return NPW_OK;
-    NPW_NCCL_CHECK(g_rccl.AllReduce(values, values, count, ncclDouble, ncclMax, c->comm, stream ? as_stream(stream) : c->stream));
-    return NPW_OK;
 }
 
 }  // extern "C"

@@ -136,13 +136,6 @@ int npw_memcpy_d2d_async(void* dst, const void* src, size_t bytes, npw_stream_t 
     return NPW_OK;
 }
 
-int npw_memcpy_peer_async(void* dst, int dst_device, const void* src, int src_device, size_t bytes,
-                          npw_stream_t stream) {
-    if (bytes == 0) return NPW_OK;
-    NPW_HIP_CHECK(hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, as_stream(stream)));
-    return NPW_OK;
-}
-
 int npw_memset_async(void* dst, int byte_value, size_t bytes, npw_stream_t stream) {
     if (bytes == 0) return NPW_OK;
     NPW_HIP_CHECK(hipMemsetAsync(dst, byte_value, bytes, as_stream(stream)));

@@ -96,11 +96,30 @@ class RcclTransport(object):
         _ffi.check(self.lib.npw_comm_info(self.handle, None, None, ctypes.byref(sh)), "npw_comm_info")
         self.stream = Stream(sh.value, True, "xgmi")
         self.rank, self.world = rank, world
+        self._group = None                # open group: received tiles whose `ready` event is recorded at group end
+
+    def begin_group(self):
+        """Everything posted until end_group() leaves as ONE RCCL launch (ncclGroupStart / ncclGroupEnd): the sends and
+        receives of a group progress side by side on their links instead of one after the other on the transport
+        stream.  Every rank opens and closes its groups at the same points of the common task sequence."""
+        if self._group is None:
+            _ffi.check(self.lib.npw_comm_group_start(self.handle), "npw_comm_group_start")
+            self._group = []
+
+    def end_group(self):
+        if self._group is not None:
+            pending, self._group = self._group, None
+            _ffi.check(self.lib.npw_comm_group_end(self.handle), "npw_comm_group_end")   # the launch happens here
+            for tile in pending:
+                self.be._produced(self.stream, tile)
 
     def send(self, tile, dsts):
         be, cs = self.be, self.stream
         be._use(cs, tile)                 # after the producer; the buffer is not recycled before the send has left
-        if len(dsts) == 1:
+        if self._group is not None:
+            for d in dsts:
+                _ffi.check(self.lib.npw_send_tile(self.handle, tile.ptr, tile.nbytes, int(d), cs.handle), "npw_send_tile")
+        elif len(dsts) == 1:
             _ffi.check(self.lib.npw_send_tile(self.handle, tile.ptr, tile.nbytes, int(dsts[0]), cs.handle), "npw_send_tile")
         else:
             arr = (ctypes.c_int * len(dsts))(*[int(d) for d in dsts])
@@ -112,11 +131,15 @@ class RcclTransport(object):
         tile = be.empty(meta.shape, meta.dtype)
         be._use(cs, tile)
         _ffi.check(self.lib.npw_recv_tile(self.handle, tile.ptr, tile.nbytes, int(src), cs.handle), "npw_recv_tile")
-        be._produced(cs, tile)
+        if self._group is not None:
+            self._group.append(tile)      # the kernel is launched by end_group(): the event goes behind it
+        else:
+            be._produced(cs, tile)
         tile.upper = meta.upper
         return tile
 
     def flush(self):
+        self.end_group()
         self.be.stream_sync(self.stream)
 
     def close(self):
@@ -134,6 +157,13 @@ class HostTransport(object):
         import torch
         self.torch, self.control = torch, control
         self.rank, self.world = rank, world
+        self.groups = 0
+
+    def begin_group(self):
+        self.groups += 1      # blocking pairwise operations in the common order: a group changes nothing here
+
+    def end_group(self):
+        pass
 
     def send(self, tile, dsts):
         arr = np.ascontiguousarray(get_backend().to_host(tile))
@@ -230,14 +260,22 @@ class Comm(object):
         h = hdr.numpy()
         return TileMeta(tuple(int(x) for x in h[1:1 + int(h[0])]), _DTYPES[int(h[5]) & 15], bool(int(h[5]) & 16))
 
-    def send_tile(self, tile, dsts, known=False):
+    def send_tile(self, tile, dsts, known=False, meta=None):
         """Push `tile` to the ranks `dsts` (one grouped launch on the transport stream).  known=True: the receivers
-        derived the tile's shape and dtype from the static plan (TileMetaPlan), nothing but the payload travels;
-        otherwise a 48-byte header goes ahead of it over the control group."""
+        derived the tile's shape and dtype from the static plan (TileMetaPlan), nothing but the payload travels --
+        `meta` is that plan entry and the tile is checked against it HERE, on the owner: the receiver has posted a
+        receive of meta.nbytes, and a payload of another size would hang or truncate inside RCCL instead of failing.
+        Otherwise a 48-byte header goes ahead of the payload over the control group."""
         if isinstance(dsts, int):
             dsts = [dsts]
         if len(tile.shape) > 4:
             raise ValueError("tiles with more than 4 dimensions cannot be exchanged")
+        if known and meta is not None:
+            if (int(tile.nbytes) != meta.nbytes or np.dtype(tile.dtype) != meta.dtype
+                    or int(np.prod(tile.shape, dtype=np.int64)) != int(np.prod(meta.shape, dtype=np.int64))):
+                raise RuntimeError("tile to be sent to ranks {0} is {1} {2} ({3} bytes) but the static plan promised its "
+                                   "receivers {4} {5} ({6} bytes)".format(list(dsts), tuple(tile.shape), np.dtype(tile.dtype),
+                                                                          tile.nbytes, meta.shape, meta.dtype, meta.nbytes))
         if not known:
             for d in dsts:
                 self._send_header(tile, d)
@@ -420,6 +458,9 @@ def _stored_tile(bigm, idx):
     return bigm.get_tile(*idx)
 
 
+TIMEOUT_CHECK_EVERY = 32     # positions of the common task sequence between two collective looks at the clock
+
+
 def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, max_inflight=64):
     """Distributed counterpart of job_runner.lambdapack_run: every rank calls it with the same program.
 
@@ -461,19 +502,30 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
                         moves.setdefault(r, (home, []))
                         if consumer not in moves[r][1]:
                             moves[r][1].append(consumer)
+        # the prologue is ONE grouped exchange: every link carries its input tiles at once (the GEMM program's A / B
+        # panels: SUMMA's traffic as a single all-to-all-v launch instead of a queue of single transfers)
+        comm.transport.begin_group()
         for r, (home, consumers) in moves.items():
             meta = metas.read(*r)
             if rank == home:
-                comm.send_tile(_stored_tile(mats[r[0]], r[1]), consumers, known=meta is not None)
+                comm.send_tile(_stored_tile(mats[r[0]], r[1]), consumers, known=meta is not None, meta=meta)
             elif rank in consumers:
                 mats[r[0]].put_tile(comm.recv_tile(home, meta), *r[1])
+        comm.transport.end_group()
+        step, timed_out = 0, False
         while program.program_status() == lp.PS.RUNNING and not program.all_terminators_done():
             node = program.dequeue()
             if node is None:
                 break
-            if time.time() - t_start > timeout:
-                program._enqueue(node)
-                break
+            # The time limit is a COLLECTIVE decision, taken at fixed positions of the common task sequence on the maximum
+            # over the ranks: a rank that left the walk on its own clock while its peers post the next transfer would
+            # leave them waiting inside RCCL for ever.  Every other decision in this loop is a function of the plan.
+            if timeout is not None and step % TIMEOUT_CHECK_EVERY == TIMEOUT_CHECK_EVERY - 1:
+                if comm.max_over_ranks(time.time() - t_start) > timeout:
+                    program._enqueue(node)
+                    timed_out = True
+                    break
+            step += 1
             e, v = node
             # every rank forms the same group of ready tasks of one batchable kind and runs its own members of it as
             # one batched launch sequence; the exchange plan below is then walked in the common order
@@ -496,7 +548,9 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
                     inflight.append(last)
                     if len(inflight) > max_inflight:
                         be.wait_tile(inflight.popleft())
-            # push the outputs to the remote consumers: both sides evaluate the same static plan here
+            # push the outputs to the remote consumers: both sides evaluate the same static plan here; the transfers of
+            # one group of tasks (the right-hand sides of a batched solve, the nodes of a tree level) are one launch
+            comm.transport.begin_group()
             for (ge, gv), task, owner in zip(group, tasks, owners):
                 kname = getattr(compiled.kernel(ge), "__name__", "")
                 out_metas = metas.visit(task, kname)
@@ -504,12 +558,13 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
                     name, idx = task.writes[pos]
                     meta = out_metas[pos] if out_metas is not None else None
                     if rank == owner:
-                        comm.send_tile(_stored_tile(mats[name], idx), ranks, known=meta is not None)
+                        comm.send_tile(_stored_tile(mats[name], idx), ranks, known=meta is not None, meta=meta)
                         ex.sent(name, idx)
                     elif rank in ranks:
                         mats[name].put_tile(comm.recv_tile(owner, meta), *idx)
                 program.post_op(ge, gv, lp.PS.SUCCESS, None)
                 program.set_node_status(ge, gv, lp.NS.FINISHED)
+            comm.transport.end_group()
         comm.flush()
         be.synchronize()
         ok = job_runner.check_info_flags(program, be)
@@ -527,7 +582,7 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
     return {"up_time": [t_start, time.time()], "exec_time": [], "executed_messages": executed,
             "operator_refs": [tuple(x) for x in executed], "log": pickle.dumps({}),
             "bytes_sent": comm.bytes_sent, "bytes_received": comm.bytes_received, "transfers": comm.transfers,
-            "headers": comm.headers}
+            "headers": comm.headers, "timed_out": timed_out, "steps": step}
 
 
 def gather_matrix(bigm, comm, root=0):

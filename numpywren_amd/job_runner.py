@@ -81,6 +81,9 @@ class LambdaPackExecutor(object):
         cfg = (program.config or {}).get("executor", {}) if isinstance(program.config, dict) else {}
         self.exact_zero = cfg.get("exact_zero_shortcircuit", True) if exact_zero is None else exact_zero
         self.reclaim = cfg.get("reclaim_intermediates", False)
+        # tiles NO task reads (TSQR's V / T factors) are part of what the reference's wrapper returns (alg_wrappers.py:47):
+        # they are only dropped on store when the caller asks for it by name (an R-only TSQR)
+        self.drop_unread = bool(cfg.get("drop_unread_outputs", False))
         self.batch_tasks = max(1, int(cfg.get("batch_tasks", 32)))
         pool = getattr(self.be, "bulk_streams", None) or self.be.streams
         n = max(1, min(int(pipeline_width), len(pool)))
@@ -110,16 +113,17 @@ class LambdaPackExecutor(object):
         self._rr += 1
         return s
 
-    # ---- reclaim bookkeeping: tiles of non-input / non-output matrices die after their last reader; a tile of such a
-    #      matrix that NO task reads (the V and T factors of the TSQR program: only R goes up the tree) dies as soon as it
-    #      has been stored -- with `reclaim_intermediates` the caller has said that only the program's outputs matter ----
+    # ---- reclaim bookkeeping: tiles of non-input / non-output matrices die after their last reader.  A tile of such a
+    #      matrix that NO task reads (the V and T factors of the TSQR program: only R goes up the tree) is kept -- the
+    #      reference persists it -- unless `drop_unread_outputs` says the caller wants the compiled outputs only ----
     def _init_reclaim(self):
         left = collections.Counter()
         keep = set(self.compiled.inputs) | set(self.compiled.outputs)
         read_by_anyone = set()
         for t in self.compiled.tasks:
             read_by_anyone.update(t.reads)
-        self._unread = {w for t in self.compiled.tasks for w in t.writes if w[0] not in keep and w not in read_by_anyone}
+        self._unread = ({w for t in self.compiled.tasks for w in t.writes if w[0] not in keep and w not in read_by_anyone}
+                        if self.drop_unread else set())
         for t in self.compiled.tasks:
             local = self.is_local is None or self.is_local(t)
             if local:

@@ -96,18 +96,26 @@ def test_reclaim_intermediates(oracle_backend):
     assert len(X.block_idxs_exist) == 16                           # inputs are never reclaimed
 
 
-def test_reclaim_drops_tiles_nobody_reads_at_once(oracle_backend):
-    """TSQR with reclaim_intermediates: V and T of every node are written and never read (only R goes up the tree), so
-    they are dropped as soon as they are stored; the R factors below the root die after their parent; the result stays."""
+@pytest.mark.parametrize("r_only", [False, True])
+def test_reclaim_keeps_v_t_unless_r_only(r_only, oracle_backend):
+    """TSQR: V and T of every node are written and never read (only R goes up the tree).  The reference's wrapper
+    returns them (alg_wrappers.py:47), so `reclaim_intermediates` alone keeps them; with `drop_unread_outputs` (an
+    explicit R-only run) they are dropped as soon as they are stored.  Either way the R factors below the root die
+    after their parent and the result stays."""
     Xh = ALG["tsqr_64_8/X"]
     X = BigMatrix("tsqr_reclaim", shape=Xh.shape, shard_sizes=(8, Xh.shape[1]))
     shard_matrix(X, Xh)
     program, meta = alg_wrappers.tsqr(X)
     program.config["executor"]["reclaim_intermediates"] = True
+    program.config["executor"]["drop_unread_outputs"] = r_only
     run(program)
     assert program.program_status() == lp.PS.SUCCESS
     R, V, T = meta["outputs"]
-    assert V.block_idxs_exist == [] and T.block_idxs_exist == []
+    if r_only:
+        assert V.block_idxs_exist == [] and T.block_idxs_exist == []
+    else:
+        nodes = [(0, j) for j in range(8)] + [(1, 0), (1, 2), (1, 4), (1, 6), (2, 0), (2, 4), (3, 0)]
+        assert all(V.tile_exists(*n) and T.tile_exists(*n) for n in nodes)          # 8 leaves + 7 tree nodes
     np.testing.assert_allclose(np.abs(R.get_block(3, 0)), np.abs(ALG["tsqr_64_8/R_final"]), atol=1e-12)
     assert len(X.block_idxs_exist) == 8                            # inputs are never reclaimed
 

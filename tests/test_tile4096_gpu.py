@@ -324,3 +324,151 @@ def test_batched_launch_forms_4096_equal_single_launches():
     solved = be.trsm_batched(L, Y)
     for i in range(3):
         assert same(solved[i], be.trsm(L, Y[i]))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[2] / [3] / [4] at their FULL size on the one GPU of the test box: the
+# 65536^2 Cholesky, the 256-leaf TSQR (1048576 x 4096) and the 32768^2 fp32 GEMM program all fit 288 GB of HBM.
+# Generators follow the reference's experiments (experiments/cholesky_experiment.py:78-92 builds X X^T + shift,
+# tsqr_experiment.py:76-98 and gemm_experiment.py shard Gaussian matrices) with bench.py's well-conditioned shift
+# (the experiment's own 20e12 N shift makes syrk's allclose short-circuit skip every update).
+# ---------------------------------------------------------------------------------------------------------------
+def test_config2_cholesky_65536_full_residual(hbm_store):
+    """configs[2]'s matrix on one GPU: 65536^2 fp64, 4096^2 tiles, 816 tasks (the reference's count), and the FULL
+    residual || A - L L^T ||_F / || A ||_F over all 136 lower tiles <= 1e-12, computed on the device."""
+    import bench
+    be = get_backend()
+    nb = 16
+    X = bench.build_input(be, nb, B, "t4096_chol65536")
+    program, meta = alg_wrappers.cholesky(X)
+    program.config["executor"]["reclaim_intermediates"] = True
+    program.start()
+    res_run = job_runner.lambdapack_run(program, timeout=1200)
+    program.wait()
+    assert program.program_status() == lp.PS.SUCCESS, program.exceptions
+    assert len(res_run["executed_messages"]) == nb * (nb + 1) * (nb + 2) // 6 == 816
+    O = meta["outputs"][0]
+    res = bench.cholesky_residual(be, X, O, nb, full=True)
+    assert res <= 1e-12, res
+    assert res < 1e-14, res          # what the kernels deliver
+    # the intermediates were reclaimed, the factor's 136 lower tiles exist, nothing above the diagonal
+    assert sum(1 for i in range(nb) for j in range(nb) if O.tile_exists(i, j)) == nb * (nb + 1) // 2
+    assert not O.tile_exists(3, 9)
+    assert not np.triu(be.to_host(be.block(O.get_tile(15, 15), 0, 512, 0, 512)), 1).any()
+    program.free()
+    X.free()
+
+
+def _tsqr_input(be, leaves, key):
+    X = BigMatrix(key, shape=(leaves * B, B), shard_sizes=(B, B))
+    for j in range(leaves):
+        X.put_tile(be.fill_random((B, B), 7, j * B, 0), j, 0)
+    return X
+
+
+def _gram(be, X, leaves):
+    G = None
+    for j in range(leaves):
+        t = X.get_tile(j, 0)
+        G = be.gemm(t, t, True, False, alpha=1.0, beta=1.0 if G else 0.0, C=G)
+    return G
+
+
+def test_config3_tsqr_256_leaves_r_only(hbm_store):
+    """configs[3]'s input on one GPU: 1048576 x 4096 fp64, 256 leaves, 511 tasks.  With `reclaim_intermediates` +
+    `drop_unread_outputs` the V / T factors (which no task reads; ~290 GB) are dropped as they are stored -- the
+    R-only form bench.py times on fewer than 4 GPUs; R^T R = A^T A to 1e-11."""
+    be = get_backend()
+    leaves = 256
+    X = _tsqr_input(be, leaves, "t4096_tsqr256")
+    program, meta = alg_wrappers.tsqr(X)
+    program.config["executor"]["reclaim_intermediates"] = True
+    program.config["executor"]["drop_unread_outputs"] = True
+    program.start()
+    res_run = job_runner.lambdapack_run(program, pipeline_width=2, timeout=1200)
+    program.wait()
+    assert program.program_status() == lp.PS.SUCCESS, program.exceptions
+    assert len(res_run["executed_messages"]) == 2 * leaves - 1
+    Rs, Vs, Ts = meta["outputs"]
+    R = Rs.get_tile(8, 0)
+    G = _gram(be, X, leaves)
+    err = np.sqrt(be.sumsq(be.gemm(R, R, True, False, alpha=1.0, beta=-1.0, C=G)) / be.sumsq(G))
+    assert err <= 1e-11 and err < 1e-13, err
+    assert not np.tril(be.to_host(R), -1).any()
+    assert not Vs.tile_exists(8, 0) and not Ts.tile_exists(0, 5)      # dropped on store
+    program.free()
+    X.free()
+
+
+def test_config3_tsqr_64_leaves_keeps_v_t(hbm_store):
+    """The same program keeping what the reference's wrapper returns (alg_wrappers.py:47: [R, V, T]): 64 leaves, every
+    V / T tile stays in HBM; the top node's factors reproduce its operands, (I - V T V^T) [R; 0] = [R_left; R_right]
+    to 1e-13, a leaf's reproduce its input tile, and R^T R = A^T A."""
+    be = get_backend()
+    leaves = 64
+    X = _tsqr_input(be, leaves, "t4096_tsqr64")
+    program, meta = alg_wrappers.tsqr(X)
+    program.config["executor"]["reclaim_intermediates"] = True      # on its own this no longer drops V / T
+    _run(program, pipeline_width=2)
+    assert program.program_status() == lp.PS.SUCCESS, program.exceptions
+    Rs, Vs, Ts = meta["outputs"]
+    top = 6
+    assert all(Vs.tile_exists(0, j) and Ts.tile_exists(0, j) for j in range(leaves))
+    assert all(Vs.tile_exists(lv, 0) and Ts.tile_exists(lv, 0) for lv in range(1, top + 1))
+    R = Rs.get_tile(top, 0)
+    G = _gram(be, X, leaves)
+    err = np.sqrt(be.sumsq(be.gemm(R, R, True, False, alpha=1.0, beta=-1.0, C=G)) / be.sumsq(G))
+    assert err <= 1e-11 and err < 1e-13, err
+
+    def reconstruct(V, T, R, operand_rows):
+        """|| (I - V T V^T) [R; 0] - operands ||_F / || operands ||_F on the device; V is (rows x B)."""
+        Vtop = be.block(V, 0, B, 0, B)
+        W = be.gemm(T, be.gemm(Vtop, R, True, False), False, False)          # T (V1^T R)
+        num = den = 0.0
+        for blk, operand in enumerate(operand_rows):
+            Vb = be.block(V, blk * B, (blk + 1) * B, 0, B)
+            Q = be.gemm(Vb, W, False, False, alpha=-1.0, beta=1.0 if blk == 0 else 0.0, C=R if blk == 0 else None)
+            num += be.sumsq(be.axpby(1.0, Q, -1.0, operand))
+            den += be.sumsq(operand)
+        return np.sqrt(num / den)
+
+    V, T = Vs.get_tile(top, 0), Ts.get_tile(top, 0)
+    assert V.shape == (2 * B, B) and T.shape == (B, B)
+    assert reconstruct(V, T, R, [Rs.get_tile(top - 1, 0), Rs.get_tile(top - 1, 32)]) < 1e-13
+    assert reconstruct(Vs.get_tile(0, 17), Ts.get_tile(0, 17), Rs.get_tile(0, 17), [X.get_tile(17, 0)]) < 1e-13
+    program.free()
+    X.free()
+
+
+def test_config4_gemm32_32768(hbm_store):
+    """configs[4] at full size on one GPU: the 32768^2 fp32 GEMM program (512 products + the reference's fan-in-4
+    add_matrices tree) against the fp64 product on sampled rows of 8 output tiles -- one in every block row and every
+    block column; tolerance of SURVEY 8(d) row 5: allclose(rtol 1e-3, atol 1e-2 sqrt(K))."""
+    be = get_backend()
+    nb = 8
+    n = nb * B
+    A = BigMatrix("t4096_gA32768", shape=(n, n), shard_sizes=(B, B), dtype=np.float32)
+    Bm = BigMatrix("t4096_gB32768", shape=(n, n), shard_sizes=(B, B), dtype=np.float32)
+    for i in range(nb):
+        for j in range(nb):
+            A.put_tile(be.convert(be.fill_random((B, B), 11, i * B, j * B), np.float32), i, j)
+            Bm.put_tile(be.convert(be.fill_random((B, B), 12, i * B, j * B), np.float32), i, j)
+    program, meta = alg_wrappers.gemm(A, Bm)
+    program.config["executor"]["reclaim_intermediates"] = True
+    _run(program)
+    assert program.program_status() == lp.PS.SUCCESS, program.exceptions
+    C = meta["outputs"][0]
+    rows = ROWS[::8]
+    cols_of = {0: 0, 1: 5, 2: 2, 3: 7, 4: 1, 5: 6, 6: 3, 7: 4}
+    for i, j in cols_of.items():
+        a = np.concatenate([be.to_host(A.get_tile(i, k))[rows].astype(np.float64) for k in range(nb)], axis=1)
+        ref = np.zeros((len(rows), B))
+        for k in range(nb):
+            ref += a[:, k * B:(k + 1) * B] @ be.to_host(Bm.get_tile(k, j)).astype(np.float64)
+        got = be.to_host(C.get_tile(i, j))
+        assert got.dtype == np.float64          # reference quirk a5: add_matrices promotes
+        np.testing.assert_allclose(got[rows], ref, rtol=1e-3, atol=1e-2 * np.sqrt(n), err_msg=f"C[{i},{j}]")
+        assert np.abs(got[rows] - ref).max() < 2e-5 * n      # fp32 products, fp64 tree: far inside the bar
+    program.free()
+    A.free()
+    Bm.free()

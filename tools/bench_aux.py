@@ -29,11 +29,13 @@ from numpywren_amd.matrix import BigMatrix  # noqa: E402
 
 
 STREAMS = 1
+R_ONLY = True    # tsqr: drop the V / T factors nobody reads as they are stored (--keep-vt turns it off)
 BATCH = None
 
 
 def run(program, reclaim=True):
     program.config["executor"]["reclaim_intermediates"] = reclaim
+    program.config["executor"]["drop_unread_outputs"] = reclaim and R_ONLY
     if BATCH is not None:
         program.config["executor"]["batch_tasks"] = BATCH
     program.start()
@@ -75,9 +77,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=1, help="HIP streams of the executor (pipeline_width)")
     ap.add_argument("--batch", type=int, default=None, help="executor.batch_tasks (ready tasks per batched launch)")
+    ap.add_argument("--keep-vt", action="store_true", help="tsqr: keep the V / T factors (the reference's full output set)")
     a = ap.parse_args()
-    global STREAMS, BATCH
+    global STREAMS, BATCH, R_ONLY
     STREAMS = a.streams
+    R_ONLY = not a.keep_vt
     BATCH = a.batch
     os.environ.setdefault("NUMPYWREN_AMD_STREAMS", str(max(4, a.streams)))
     be = get_backend()
