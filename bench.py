@@ -33,6 +33,11 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense fp64 matrix peak (vendor spec; 74.6 measured by tools/devcheck)
 TILE = 4096
+# 65536^2 on ONE GPU: the anchor of the N > 1 strong-scaling lines, and the curve DESIGN.md section 6 predicts from the
+# measured kernel times (never a measured value: no multi-GPU node has been available to the builder)
+NORTH_STAR_1GPU_TFLOPS = 70.27
+NORTH_STAR_1GPU_SOURCE = "gpurun_out/r03a/bench.json north_star (driver BENCH_r02.json: 70.0)"
+PREDICTED_STRONG_SCALING = {"1": 70.3, "2": 133, "4": 247, "8": 420}
 SYRK_TRAFFIC_BYTES = 3.78e9    # PMC passes of a separate run (2 x FETCH_SIZE + WRITE_SIZE per one-tile launch of the tagged kernel)
 SYRK_TRAFFIC_SOURCE = "profiles/r02_bench_pmc_final.json (rocprofv3 --pmc, separate passes)"
 
@@ -113,7 +118,9 @@ def cpu_baseline(b, budget_s=12.0):
 
     out = {"unit": "TFLOP/s", "kind": "port", "blas": _blas_name(), "probe_syrk_2048_gflops_by_threads": sweep}
     for label, th in (("best", best), ("one_thread", 1)):
-        nb = next((k for k in (4, 3, 2, 1) if executed(k) / (sweep[th] * 1e9 * 0.7) < budget_s), 1)
+        # the best setting always runs configs[1]'s own 16384^2 matrix (10 - 25 s on these hosts), so that `value` means
+        # the same on every box of the pool; the 1-thread sample is sized to the budget
+        nb = 4 if label == "best" else next((k for k in (4, 3, 2, 1) if executed(k) / (sweep[th] * 1e9 * 0.7) < budget_s), 1)
         with _blas_threads(th):
             n, dt = _oracle_tile_cholesky(oracle, b, nb, rng)
         out[label] = {"threads": th, "tflops": round((n ** 3 / 3) / dt / 1e12, 4), "n": n, "seconds": round(dt, 2)}
@@ -167,6 +174,7 @@ class Runner(object):
     def __init__(self, be, comm, streams, priority_stream=False, r_only=False):
         self.be, self.comm, self.streams, self.priority_stream = be, comm, streams, priority_stream
         self.r_only = r_only    # TSQR: drop the V / T factors no task reads as they are stored (executor.drop_unread_outputs)
+        self.fuse = False       # GEMM program: executor.fuse_gemm_reduction (the accumulate-in-place mode)
         self.pending = []   # (program, meta) enqueued on the device, not yet waited for
 
     def settle(self):
@@ -189,6 +197,7 @@ class Runner(object):
             m.free()
         program.config["executor"]["reclaim_intermediates"] = True
         program.config["executor"]["drop_unread_outputs"] = self.r_only
+        program.config["executor"]["fuse_gemm_reduction"] = self.fuse
         program.config["executor"]["priority_stream"] = self.priority_stream
         program.start()
         if self.comm is None:
@@ -420,9 +429,27 @@ def main():
                 "config": {"workload": f"{n}x{n} fp32 GEMM, {b}^2 tiles, alg_wrappers.gemm (fp32 MFMA products, fp64 "
                                        f"add_matrices tree as in the reference)", "tile": b, "streams": args.streams,
                            "parallelism": par, "pct_fp32_mfma_peak": round(100 * value / (157.3 * args.gpus), 2)}}
+        if comm is None:
+            # beside the parity mode (`value`): the same program with executor.fuse_gemm_reduction -- the K partial
+            # products of a C tile accumulate in one fp32 buffer, no Temp tiles, no add_matrices tree
+            run.fuse = True
+            e2, _ = run.timed(lambda: alg_wrappers.gemm(A, B), args.steps, 1)
+            run.fuse = False
+            fused = args.steps * 2.0 * n ** 3 / e2 / 1e12
+            line["config"]["fused_tflops"] = round(fused, 3)
+            line["config"]["fused_ms_per_step"] = round(e2 / args.steps * 1e3, 3)
+            line["config"]["fused_pct_fp32_mfma_peak"] = round(100 * fused / 157.3, 2)
+            line["config"]["fused_mode"] = "executor.fuse_gemm_reduction: fp32 accumulation in place, result converted to fp64 once"
     if comm is not None:
         line["config"]["transport"] = comm.backend
         line["config"]["bytes_sent_rank0"] = comm.bytes_sent
+        if args.workload == "chol" and world > 1:
+            # the N = 1 point of THIS curve is not the N = 1 line's `value` (configs[1]: 16384^2, what BASELINE.json
+            # asks that line to report) but its `north_star` object: the same 65536^2 matrix on one GPU
+            line["config"]["strong_scaling_anchor"] = {
+                "what": "the same matrix on 1 GPU = `north_star.tflops` of the N = 1 line (or `bench.py --tiles 16`)",
+                "tflops_last_measured": NORTH_STAR_1GPU_TFLOPS, "source": NORTH_STAR_1GPU_SOURCE,
+                "predicted_tflops_by_gpus": PREDICTED_STRONG_SCALING}
     if rank == 0:
         print(json.dumps(line))
     if comm is not None:

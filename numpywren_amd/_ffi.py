@@ -33,6 +33,7 @@ PROTOTYPES = {
     "npw_get_device": (c_int, [POINTER(c_int)]),
     "npw_device_info": (c_int, [c_int, c_char_p, _sz, POINTER(_sz), POINTER(c_int), POINTER(c_int)]),
     "npw_mem_info": (c_int, [POINTER(_sz), POINTER(_sz)]),
+    "npw_device_pci_bus_id": (c_int, [c_int, c_char_p, _sz]),
     "npw_malloc": (c_int, [POINTER(_vp), _sz]),
     "npw_free": (c_int, [_vp]),
     "npw_host_alloc": (c_int, [POINTER(_vp), _sz]),

@@ -18,6 +18,10 @@ DEFAULTS = {
         # also drop, as soon as they are stored, tiles of such matrices that NO task reads (TSQR's V / T factors, which
         # the reference's wrapper returns next to R, alg_wrappers.py:47): an explicit "R only" request, never implied
         "drop_unread_outputs": False,
+        # GEMM program: accumulate the K partial products of a C tile in ONE buffer (beta = 1 on the GEMM's accumulator:
+        # fp32 for fp32 tiles) instead of materialising Temp[i, j, k, l] and summing them with the fp64 add_matrices
+        # tree (job_runner.ReductionFusion).  Off = the reference's arithmetic, task by task (the parity mode).
+        "fuse_gemm_reduction": False,
         # Ready tasks of one latency-bound kind (qr_factor: the TSQR leaves, the nodes of a tree level) that are
         # handed to the device as a single batched launch sequence; 1 = one task at a time.  32 = what the QR panel kernel
         # holds at once for 4096-row tiles (2 workgroups per CU x 256 CUs / 16 slabs); 128-leaf TSQR: 1046 ms with 16,

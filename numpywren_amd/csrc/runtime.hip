@@ -84,6 +84,13 @@ int npw_device_info(int device, char* name, size_t name_len, size_t* total_mem_b
     return NPW_OK;
 }
 
+int npw_device_pci_bus_id(int device, char* out, size_t out_len) {
+    NPW_REQUIRE(out != nullptr && out_len >= 16, "npw_device_pci_bus_id: need a buffer of at least 16 bytes");
+    out[0] = 0;
+    NPW_HIP_CHECK(hipDeviceGetPCIBusId(out, (int)out_len, device));
+    return NPW_OK;
+}
+
 int npw_mem_info(size_t* free_bytes, size_t* total_bytes) {
     size_t f = 0, t = 0;
     NPW_HIP_CHECK(hipMemGetInfo(&f, &t));

@@ -314,13 +314,31 @@ def init_process_group(backend=None):
     use_rccl = False
     if "gloo" not in want:
         from .device import hip_available
+        # RCCL needs every rank of the communicator on its OWN physical GPU.  Device counts do not tell: under torchrun
+        # with per-rank HIP_VISIBLE_DEVICES every rank sees one device and they are all different; on a one-GPU test
+        # box every rank sees one device and it is the same.  So the ranks compare the PCI bus id of the device each
+        # of them will bind (LOCAL_RANK mod visible devices, like HipBackend) over the control group.
+        mine = None
         if hip_available():
             n = ctypes.c_int(0)
             _ffi.lib().npw_device_count(ctypes.byref(n))
-            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-            use_rccl = n.value >= local_world          # one device per rank, or the ranks cannot all hold a communicator
-            if not use_rccl and want in ("rccl", "nccl"):
-                raise RuntimeError(f"RCCL transport needs one GPU per rank ({local_world} ranks, {n.value} devices)")
+            if n.value > 0:
+                buf = ctypes.create_string_buffer(64)
+                dev = int(os.environ.get("LOCAL_RANK", "0")) % n.value
+                if _ffi.lib().npw_device_pci_bus_id(dev, buf, 64) == 0:
+                    mine = buf.value.decode()
+        ids = [None] * world
+        if world > 1:
+            dist.all_gather_object(ids, mine)
+        else:
+            ids = [mine]
+        use_rccl = all(i is not None for i in ids) and len(set(ids)) == world
+        if not use_rccl and want in ("rccl", "nccl"):
+            raise RuntimeError(f"RCCL transport needs one GPU per rank; the ranks sit on {ids}")
+        if not use_rccl and mine is not None and rank == 0:
+            import warnings
+            warnings.warn("numpywren_amd.dist: ranks share a GPU (PCI bus ids {0}): tiles are staged through host memory "
+                          "over the gloo control group, not sent over RCCL / xGMI".format(ids))
     transport = (RcclTransport if use_rccl else HostTransport)(rank, world, dist)
     return Comm(rank, world, transport, dist)
 

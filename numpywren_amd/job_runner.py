@@ -68,6 +68,109 @@ def calculate_busy_time(rtimes):
     return out
 
 
+class ReductionFusion(object):
+    """`executor.fuse_gemm_reduction`: the GEMM program's `Temp` + `add_matrices` tree as an accumulation in place.
+
+    The reference computes C[i, j] as K separate tile products Temp[i, j, k, 0] = gemm(A[i, k], B[k, j]) followed by a
+    fan-in-4 tree of add_matrices tasks (reference algs.py:251-266, kernels.py:16-20): every partial product is written
+    to and read back from the object store.  With tiles resident in HBM the same sum is one buffer per C tile that every
+    product accumulates into (beta = 1 on the GEMM's own accumulator type: fp32 products of fp32 tiles accumulate in
+    fp32), and the tree's tasks have nothing left to do but hand that buffer on; the last one converts it to float64,
+    the dtype add_matrices promotes to, so the output matrix has the reference's dtype either way.  Which tasks fuse is
+    read off the compiled DAG, not off the program's name: an add_matrices task fuses when each of its operands is (a)
+    the output of a `gemm` task, or of an add_matrices task that fuses itself, which nobody else reads, or (b) a tile no
+    task writes in a matrix whose parent_fn is constant_zeros (the tree's padding).  The default -- the parity mode --
+    materialises every Temp tile like the reference."""
+
+    def __init__(self, compiled):
+        self.compiled = compiled
+        readers = collections.defaultdict(list)
+        for t in compiled.tasks:
+            for r in set(t.reads):
+                readers[r].append(t)
+        name = lambda t: getattr(compiled.kernel(t.expr_idx), "__name__", "")
+        fus = {}
+
+        def zero_pad(r):
+            m = compiled.matrices[r[0]]
+            return (compiled.writer_of(*r) is None and r[0] not in compiled.inputs
+                    and getattr(getattr(m, "parent_fn", None), "_npw_zero_shape", None) is not None)
+
+        def fusable(t):
+            if t.index in fus:
+                return fus[t.index]
+            ok = name(t) == "add_matrices" and len(t.writes) == 1 and not t.kwargs
+            if ok:
+                for r in t.reads:
+                    w = compiled.writer_of(*r)
+                    if w is None:
+                        ok = zero_pad(r)
+                    else:
+                        only_me = all(x is t for x in readers[r])
+                        ok = only_me and len(w.writes) == 1 and ((name(w) == "gemm" and len(w.reads) == 2) or fusable(w))
+                    if not ok:
+                        break
+            fus[t.index] = ok
+            return ok
+
+        self.root_of = {}        # task index (gemm leaf or fused add) -> index of the add task that stores the sum
+        self.roots = {}          # root add task index -> number of products it sums
+        for t in compiled.tasks:
+            if not fusable(t):
+                continue
+            consumers = readers.get(t.writes[0], [])
+            if len(consumers) == 1 and fusable(consumers[0]) and t.writes[0] in consumers[0].reads:
+                continue         # an inner node of the tree
+            stack, leaves = [t], 0
+            while stack:
+                a = stack.pop()
+                self.root_of[a.index] = t.index
+                for r in a.reads:
+                    w = compiled.writer_of(*r)
+                    if w is None:
+                        continue
+                    if name(w) == "gemm":
+                        self.root_of[w.index] = t.index
+                        leaves += 1
+                    else:
+                        stack.append(w)
+            self.roots[t.index] = leaves
+        self.acc = {}            # root index -> the accumulating DeviceTile
+
+    def handles(self, task):
+        return task.index in self.root_of
+
+    def run(self, ex, task, compute, stream):
+        """The fused counterpart of one task; returns the tile the task stores (None: nothing)."""
+        be = ex.be
+        root = self.root_of[task.index]
+        mats = self.compiled.matrices
+        if getattr(compute, "__name__", "") == "gemm":
+            tiles = [mats[m].get_tile(*idx, stream=stream) for m, idx in task.reads]
+            args = [tiles[j] if kind == "tile" else task.consts[j] for kind, j in task.arg_kinds]
+            A, B = [a for a in args if isinstance(a, DeviceTile)][:2]
+            acc = self.acc.get(root)
+            ta, tb = bool(task.kwargs.get("transpose_A", False)), bool(task.kwargs.get("transpose_B", False))
+            if acc is None:
+                self.acc[root] = be.gemm(A, B, ta, tb, stream)
+            else:
+                self.acc[root] = be.gemm(A, B, ta, tb, stream, alpha=1.0, beta=1.0, C=acc, out=acc)
+            flops_fn = getattr(compute, "flops", None)
+            if flops_fn is not None:
+                ex.program.incr_flops(flops_fn(A, B))
+            ex.program.incr_read(sum(t.nbytes for t in tiles))
+            return None
+        if task.index != root:
+            return None                      # an inner add: its sum is still travelling in the accumulator
+        acc = self.acc.pop(root)
+        out = be.as_f64(acc, stream)         # add_matrices promotes to float64 (reference quirk a5)
+        (m, idx), = task.writes
+        mats[m].put_tile(out, *idx)
+        ex.program.incr_write(out.nbytes)
+        return out
+
+
+
 class LambdaPackExecutor(object):
     """Executes single tasks of a program on the HIP backend."""
 
@@ -99,6 +202,10 @@ class LambdaPackExecutor(object):
             self.chain_cus = 0
         self.chain_runs = 0
         self.chain_stmts = []
+        self.fusion = None
+        if cfg.get("fuse_gemm_reduction", False) and not program.block_sparse and is_local is None:
+            fusion = ReductionFusion(self.compiled)
+            self.fusion = fusion if fusion.roots else None
         if self.chain_cus:
             self.chain_stmts = [i for i, k in getattr(self.compiled, "_kernels", {}).items()
                                 if getattr(k, "_npw_chain_resident_cus", None) is not None]
@@ -248,6 +355,13 @@ class LambdaPackExecutor(object):
         mats = self.compiled.matrices
         if stream is None:
             stream = self.pick_stream(compute)
+        if self.fusion is not None and self.fusion.handles(task):
+            last = self.fusion.run(self, task, compute, stream)
+            self._consumed(task)
+            self.program.record_profile(expr_idx, var_values, kernel=getattr(compute, "__name__", str(compute)) + "+fused",
+                                        stream=getattr(stream, "name", str(stream)), enqueue_start=t_enq,
+                                        enqueue_end=time.time(), read_bytes=0, write_bytes=0, batch=1)
+            return last
         device_kernel = getattr(compute, "_npw_device_kernel", False)
         # A kernel whose workgroups need a whole CU to themselves (the Cholesky panel chain: 150 KiB of LDS each)
         # starves next to chip-filling GEMMs of other streams -- every launch then waits for ~1 ms workgroups to
@@ -433,6 +547,14 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
                             pipeline_width=pipeline_width)
     executed, refs, running_times = [], [], []
     inflight = collections.deque()
+
+    def track(last):
+        """Bound the host's run-ahead (and the tile references it pins) in EVERY branch of the loop."""
+        if last is not None and last.ready is not None:
+            inflight.append(last)
+        while len(inflight) > max_inflight:
+            be.wait_tile(inflight.popleft())
+
     program._defer_success = True
     if after:
         chain_pair = list(be.chain_streams(ex.chain_cus)) if ex.chain_cus else []
@@ -474,8 +596,7 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
                         program.set_node_status(ne, nv, lp.NS.FINISHED)
                         executed.append([ne, nv])
                         refs.append((ne, nv))
-                        if last is not None and last.ready is not None:
-                            inflight.append(last)
+                        track(last)
                     running_times.append((t0, time.time()))
                     continue
             companions = ex.chain_companions(e, v)
@@ -495,8 +616,7 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
                     refs.append((ge, gv))
                 running_times.append((t0, time.time()))
                 for last in lasts:
-                    if last is not None and last.ready is not None:
-                        inflight.append(last)
+                    track(last)
                 continue
             if ex.chain_cus and ex.batch_fn(e) is not None:
                 # before a batch swallows the ready tasks of this kind: the one whose completion makes a panel
@@ -522,8 +642,7 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
                     executed.append([e, v])
                     refs.append((e, v))
                     running_times.append((t0, time.time()))
-                    if last is not None and last.ready is not None:
-                        inflight.append(last)
+                    track(last)
                     continue
             # independent ready tasks of the same kind (TSQR leaves, the nodes of a tree level, the trailing updates of a
             # block column) go to the device as ONE batched launch sequence
@@ -546,10 +665,7 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
                 executed.append([ge, gv])
                 refs.append((ge, gv))
             running_times.append((t0, time.time()))
-            if last is not None and last.ready is not None:
-                inflight.append(last)
-                if len(inflight) > max_inflight:
-                    be.wait_tile(inflight.popleft())
+            track(last)
         # completion marks of THIS run: one event per stream it used (a device-wide synchronise would also wait for
         # whatever a pipelining caller has enqueued behind it)
         used = list(ex.streams) + ([ex.prio_stream] if ex.prio_stream is not None else [])

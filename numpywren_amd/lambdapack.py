@@ -22,6 +22,8 @@ from enum import Enum
 
 import numpy as np
 
+from .exceptions import LambdaPackTimeoutException
+
 
 class RemoteInstructionOpCodes(Enum):
     S3_LOAD = 0
@@ -490,15 +492,16 @@ class LambdaPackProgram(object):
             finish()
         status = self.program_status()
         while status == PS.RUNNING:
-            if self.get_up() == 0:
-                # Nobody is driving this program any more (a run left its loop on a timeout or on a stalled DAG) and, unlike
-                # the reference's fleet, no other worker can pick it up: report instead of sleeping forever.
+            if self.get_up() == 0 and getattr(self, "_was_up", False):
+                # A worker drove this program and left it unfinished (lambdapack_run left its loop on a timeout or on a
+                # stalled DAG) and, unlike the reference's fleet, no other worker will pick it up: say so instead of
+                # sleeping for ever.  The status stays RUNNING -- calling lambdapack_run again resumes the program --
+                # and a wait() that merely runs before the worker of another thread has come up keeps waiting.
                 with self._lock:
                     pending = len(self._ready)
-                self.handle_exception(RuntimeError(
+                raise LambdaPackTimeoutException(
                     "program is still RUNNING but no worker is up ({0} ready tasks left): lambdapack_run timed out or the "
-                    "DAG stalled; call lambdapack_run again to resume".format(pending)), tb="", expr_idx=-1, var_values={})
-                break
+                    "DAG stalled; call lambdapack_run again to resume".format(pending))
             time.sleep(sleep_time)
             status = self.program_status()
 
@@ -524,6 +527,7 @@ class LambdaPackProgram(object):
             return self._counters.get(name, 0)
 
     def incr_up(self, amount):
+        self._was_up = True
         self._incr(self.up, amount)
 
     def decr_up(self, amount):

@@ -136,6 +136,9 @@ class OracleBackend(object):
         r = alpha * oracle.gemm(A.array, B.array, transpose_A=transpose_A, transpose_B=transpose_B)
         if C is not None and beta != 0:
             r = r + beta * C.array
+        if out is not None:
+            out.array[...] = r.astype(out.array.dtype)
+            return out
         return HostTile(r)
 
     def syrk(self, S, X, Y, stream=None, inplace=False, exact_zero=True):

@@ -2,7 +2,7 @@
 
 A single device cannot hold two ranks of one communicator, so what runs here is everything that does not need a
 second GPU: loading librccl on demand, rendezvous id + communicator creation, the transport stream, a grouped
-self send/receive of a real tile through ncclSend / ncclRecv, the degenerate collectives of a world of one, and the
+self send/receive of a real tile through ncclSend / ncclRecv (bare and through dist.py's grouped transport), and the
 distributed executor over the RCCL transport (`dist.init_process_group()` -> RcclTransport) for a world of one.  The
 exchange logic for world > 1 is covered with the host transport in tests/test_dist_gloo.py (CPU, world 2 / 4) and
 tests/test_dist_gpu.py (HIP kernels, 2 / 4 ranks sharing this GPU); the driver's 8-GPU run is the first place both
@@ -46,23 +46,20 @@ def test_comm_world_of_one_self_exchange():
     _ffi.check(lib.npw_comm_group_end(h))
     be._produced(cs, dst)
     assert np.array_equal(be.to_host(dst), a)
-    # the same through the exchange helper
-    dst2 = be.zeros(a.shape)
-    be._use(cs, dst2)
-    _ffi.check(lib.npw_sendrecv_tile(h, src.ptr, src.nbytes, 0, dst2.ptr, dst2.nbytes, 0, cs.handle), "sendrecv")
-    be._produced(cs, dst2)
-    assert np.array_equal(be.to_host(dst2), a)
-    # world of one: all-gather is a copy, max-reduction the identity, a broadcast without other members a no-op
-    out = be.zeros(a.shape)
-    be._use(cs, out)
-    _ffi.check(lib.npw_allgather_tiles(h, src.ptr, out.ptr, src.nbytes, cs.handle), "allgather")
-    be._produced(cs, out)
-    assert np.array_equal(be.to_host(out), a)
-    v = be.to_device(np.array([3.5, -1.0]))
-    be._use(cs, v)
-    _ffi.check(lib.npw_allreduce_max_f64(h, v.ptr, 2, cs.handle), "allreduce")
-    be._produced(cs, v)
-    assert np.array_equal(be.to_host(v), [3.5, -1.0])
+    # the same through dist.py's transport object: a group opened with begin_group() carries a send and its receive,
+    # the received tile's event is recorded behind the launch at end_group()
+    from numpywren_amd.dist import RcclTransport, TileMeta
+    tr = RcclTransport.__new__(RcclTransport)
+    tr.be, tr.lib, tr.handle, tr.stream, tr.rank, tr.world, tr._group = be, lib, h.value, cs, 0, 1, None
+    tr.begin_group()
+    tr.send(src, [0])
+    got = tr.recv(0, TileMeta(a.shape, a.dtype))
+    tr.end_group()
+    assert tr._group is None and np.array_equal(be.to_host(got), a)
+    # the physical device's PCI bus id (what the ranks compare to decide between RCCL and host staging)
+    bus = ctypes.create_string_buffer(64)
+    _ffi.check(lib.npw_device_pci_bus_id(be.device, bus, 64), "pci_bus_id")
+    assert bus.value.count(b":") == 2
     members = (ctypes.c_int * 1)(0)
     _ffi.check(lib.npw_bcast_tile(h, src.ptr, src.nbytes, 0, members, 1, cs.handle), "bcast")
     # argument checking

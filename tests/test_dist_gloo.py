@@ -189,6 +189,43 @@ def _worker(rank, world, port, scenario, outdir):
             raise AssertionError("block_sparse must be refused")
         except NotImplementedError:
             pass
+    elif scenario == "slow_rank":
+        # One rank's host is slow and the time limit expires: the decision to stop is taken on the maximum over the
+        # ranks at fixed positions of the common task sequence, so every rank leaves the walk at the SAME position (a
+        # rank leaving on its own clock would strand its peers inside a transfer), nothing hangs, and the run can be
+        # resumed because the program is still RUNNING.
+        import time as _time
+        rng = np.random.default_rng(5)
+        nb, b = 12, 4
+        G = rng.standard_normal((nb * b, nb * b))
+        A = G @ G.T + nb * b * np.eye(nb * b)
+        X = BigMatrix("chol_slow", shape=A.shape, shard_sizes=(b, b))
+        scatter_owned(X, A, "I")
+        program, meta = alg_wrappers.cholesky(X)
+        program.start()
+        from numpywren_amd import job_runner
+        real = job_runner.LambdaPackExecutor.run_task
+
+        def slow(self, e, v, stream=None):
+            if rank == 1:
+                _time.sleep(0.01)
+            return real(self, e, v, stream=stream)
+        job_runner.LambdaPackExecutor.run_task = slow
+        dist.TIMEOUT_CHECK_EVERY = 8
+        res = dist.lambdapack_run_distributed(program, comm, timeout=0.25)
+        job_runner.LambdaPackExecutor.run_task = real
+        steps = [None] * world
+        comm.dist.all_gather_object(steps, (res["steps"], res["timed_out"]))
+        assert len(set(steps)) == 1 and steps[0][1] is True, steps          # same position everywhere
+        assert 0 < res["steps"] < nb * (nb + 1) * (nb + 2) // 6
+        assert program.program_status() == lp.PS.RUNNING
+        # resume without a limit: the program completes and the factor is right
+        res2 = dist.lambdapack_run_distributed(program, comm, timeout=None)
+        assert program.program_status() == lp.PS.SUCCESS, program.exceptions
+        assert not res2["timed_out"]
+        got = dist.gather_matrix(meta["outputs"][0], comm)
+        if rank == 0:
+            np.testing.assert_allclose(got, np.linalg.cholesky(A), rtol=1e-10, atol=1e-10)
     elif scenario == "not_pd":
         A = np.eye(32)
         A[20, 20] = -1.0
@@ -238,6 +275,11 @@ def test_tsqr_chunked_ownership_and_batches(world, tmp_path):
 
 def test_gemm_sharded(tmp_path):
     _spawn(2, "gemm", tmp_path)
+
+
+def test_time_limit_is_a_collective_decision(tmp_path):
+    """one slow rank, a short limit -- every rank stops at the same position, then resumes."""
+    _spawn(2, "slow_rank", tmp_path)
 
 
 def test_failure_reaches_every_rank(tmp_path):

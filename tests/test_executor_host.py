@@ -278,6 +278,81 @@ def test_qr(tag, b, oracle_backend):
                                        err_msg=f"R[{i},{k}]")
 
 
+@pytest.mark.parametrize("tag,b", [("32_8", 8), ("40_8", 8), ("16_8_f32", 8)])
+def test_gemm_fused_reduction(tag, b, oracle_backend):
+    """executor.fuse_gemm_reduction: the K partial products of a C tile accumulate in one buffer, no Temp tile is ever
+    stored, the add_matrices tree only hands the buffer on; same result (and output dtype) as the parity mode."""
+    from numpywren_amd.job_runner import ReductionFusion
+    A, B, C = ALG[f"gemm_{tag}/A"], ALG[f"gemm_{tag}/B"], ALG[f"gemm_{tag}/C"]
+    Ab = BigMatrix(f"gemmf_A_{tag}", shape=A.shape, shard_sizes=(b, b), dtype=A.dtype)
+    Bb = BigMatrix(f"gemmf_B_{tag}", shape=B.shape, shard_sizes=(b, b), dtype=B.dtype)
+    shard_matrix(Ab, A)
+    shard_matrix(Bb, B)
+    program, meta = alg_wrappers.gemm(Ab, Bb)
+    program.config["executor"]["fuse_gemm_reduction"] = True
+    fusion = ReductionFusion(program.program)
+    nb = A.shape[0] // b
+    assert len(fusion.roots) == nb * nb and set(fusion.roots.values()) == {nb}      # one root per C tile, K products each
+    run(program)
+    assert program.program_status() == lp.PS.SUCCESS
+    out, temp = meta["outputs"][0], meta["intermediates"][0]
+    got = out.numpy()
+    assert got.dtype == np.float64                                   # add_matrices' promotion survives the fusion
+    tol = 1e-4 if A.dtype == np.float32 else 1e-12
+    np.testing.assert_allclose(got, C, rtol=tol, atol=tol)
+    # only the tree's final tile of every C tile was stored
+    stored = sum(1 for i in range(nb) for j in range(nb) for k in range(nb) for l in range(4) if temp.tile_exists(i, j, k, l))
+    assert stored == nb * nb
+    gemms = sum(1 for c in oracle_backend.calls if c[0] == "gemm")
+    assert gemms == nb ** 3 and not any(c[0] == "add_n" for c in oracle_backend.calls)
+
+
+def test_fusion_leaves_other_programs_alone(oracle_backend):
+    """Nothing fuses in a program without the gemm -> add_matrices pattern; a Temp tile with a second reader would not
+    fuse either (the DAG decides, not the program's name)."""
+    from numpywren_amd.job_runner import ReductionFusion
+    A = ALG["cholesky_32_8/A"]
+    X = BigMatrix("fusion_chol", shape=A.shape, shard_sizes=(8, 8))
+    shard_matrix(X, A)
+    program, meta = alg_wrappers.cholesky(X)
+    assert ReductionFusion(program.program).roots == {}
+    program.config["executor"]["fuse_gemm_reduction"] = True
+    run(program)
+    np.testing.assert_allclose(meta["outputs"][0].numpy(), ALG["cholesky_32_8/L"], rtol=1e-12, atol=1e-12)
+
+
+def test_wait_after_a_timed_out_run_reports_and_the_program_resumes(oracle_backend):
+    """A run that leaves its loop on the time limit leaves the program RUNNING with no worker up: wait() raises the
+    timeout instead of sleeping for ever, does NOT fail the program, and a second lambdapack_run finishes it.  A wait()
+    that starts before any worker came up (the reference's start -> launch workers elsewhere -> wait) keeps waiting."""
+    import threading
+    from numpywren_amd.exceptions import LambdaPackTimeoutException
+    A, L = ALG["cholesky_32_8/A"], ALG["cholesky_32_8/L"]
+    X = BigMatrix("timeout_A", shape=A.shape, shard_sizes=(8, 8))
+    shard_matrix(X, A)
+    program, meta = alg_wrappers.cholesky(X)
+    program.start()
+    res = job_runner.lambdapack_run(program, timeout=-1.0)       # expires at the first task
+    assert len(res["executed_messages"]) == 0 and program.program_status() == lp.PS.RUNNING
+    with pytest.raises(LambdaPackTimeoutException):
+        program.wait(sleep_time=0.01)
+    assert program.program_status() == lp.PS.RUNNING             # still resumable
+    job_runner.lambdapack_run(program)
+    program.wait()
+    assert program.program_status() == lp.PS.SUCCESS
+    np.testing.assert_allclose(np.tril(meta["outputs"][0].numpy()), L, atol=1e-12)
+    # wait() first, worker later (another thread): no false alarm
+    X2 = BigMatrix("timeout_B", shape=A.shape, shard_sizes=(8, 8))
+    shard_matrix(X2, A)
+    program2, meta2 = alg_wrappers.cholesky(X2)
+    program2.start()
+    th = threading.Timer(0.2, lambda: job_runner.lambdapack_run(program2))
+    th.start()
+    program2.wait(sleep_time=0.02)
+    th.join()
+    assert program2.program_status() == lp.PS.SUCCESS
+
+
 def test_run_without_waiting_settles_in_program_wait(oracle_backend):
     """lambdapack_run(wait=False) only enqueues; program.wait() -- next in the reference's call sequence -- settles."""
     A, L = ALG["cholesky_32_8/A"], ALG["cholesky_32_8/L"]

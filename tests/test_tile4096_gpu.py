@@ -259,6 +259,37 @@ def test_config4_gemm32_8192(hbm_store):
     program.free()
 
 
+def test_config4_gemm32_8192_fused_equals_parity_mode(hbm_store):
+    """executor.fuse_gemm_reduction (fp32 accumulation of the K products in one buffer, no Temp / add_matrices tiles)
+    against the parity mode on the 8192^2 case with 4096^2 tiles: same dtype (fp64), equal to fp32 tolerance."""
+    be = get_backend()
+    n, nb = 2 * B, 2
+    A = BigMatrix("t4096_gAf", shape=(n, n), shard_sizes=(B, B), dtype=np.float32)
+    Bm = BigMatrix("t4096_gBf", shape=(n, n), shard_sizes=(B, B), dtype=np.float32)
+    for i in range(nb):
+        for j in range(nb):
+            A.put_tile(be.convert(be.fill_random((B, B), 21, i * B, j * B), np.float32), i, j)
+            Bm.put_tile(be.convert(be.fill_random((B, B), 22, i * B, j * B), np.float32), i, j)
+    outs = []
+    for fuse in (False, True):
+        program, meta = alg_wrappers.gemm(A, Bm)
+        program.config["executor"]["fuse_gemm_reduction"] = fuse
+        _run(program)
+        assert program.program_status() == lp.PS.SUCCESS, program.exceptions
+        C, Temp = meta["outputs"][0], meta["intermediates"][0]
+        outs.append([C.get_tile(i, j) for i in range(nb) for j in range(nb)])
+        stored = sum(1 for i in range(nb) for j in range(nb) for k in range(nb) for l in range(2) if Temp.tile_exists(i, j, k, l))
+        assert stored == (nb * nb if fuse else nb * nb * (nb + 1))
+        C.free()
+        Temp.free()
+    for p, f in zip(*outs):
+        assert p.dtype == np.float64 and f.dtype == np.float64
+        # difference of an fp32 and an fp64 sum of 2 fp32-accumulated products of length 4096: a few fp32 ulps of |C| ~ 90
+        d = np.sqrt(be.sumsq(be.axpby(1.0, p, -1.0, f)) / be.sumsq(p))
+        assert d < 1e-6, d
+        assert float(np.abs(be.to_host(be.axpby(1.0, p, -1.0, f))).max()) < 2e-5 * n
+
+
 @pytest.mark.parametrize("dtype,m,n,k", [(np.float64, 1801, 1795, 1003), (np.float32, 2048, 2048, 2048), (np.float32, 1801, 1795, 1003)])
 def test_big_tile_nt_paths(dtype, m, n, k):
     """The 128 x 128 KC/KC instantiations with the pinned store / MFMA interleave that nothing else reaches: ragged
