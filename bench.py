@@ -284,8 +284,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     os.environ.pop("NUMPYWREN_AMD_STORE", None)
     if args.streams <= 0:
-        # tsqr: two streams let the panel chain of one batch of leaves run beside the far updates of another
-        args.streams = (2 if args.workload == "tsqr" else 1) if world == 1 else 3
+        # (tsqr: one stream -- a batch of 32 factorisations fills the chip by itself; two batches side by side only fight for
+        #  workgroup slots: 1716 ms with one stream, 1940 with two on the round-3 build, gpurun_out/r03i)
+        args.streams = 1 if world == 1 else 3
 
     from numpywren_amd import alg_wrappers
     from numpywren_amd.device import get_backend

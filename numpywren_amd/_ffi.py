@@ -12,7 +12,8 @@ from ctypes import POINTER, c_char, c_char_p, c_double, c_float, c_int, c_int32,
 
 from .exceptions import HipExtensionError, NpwHipError
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libnpw_hip.so")
+# ($NUMPYWREN_AMD_LIB: another build of the same library, for A/B timing runs of the developer tools)
+_LIB_PATH = os.environ.get("NUMPYWREN_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libnpw_hip.so")
 _lib = None
 _lock = threading.Lock()
 

@@ -87,6 +87,8 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
 struct SideStream {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
+    hipStream_t stream2 = nullptr;            // a second helper stream (QR: the next block's near updates, off the panel chain)
+    hipEvent_t fork2 = nullptr, join2 = nullptr;
 };
 int side_stream(hipStream_t main, SideStream** out);
 

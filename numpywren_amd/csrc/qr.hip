@@ -30,7 +30,8 @@ __device__ inline double wave_sum(double v) {
     return v;
 }
 
-constexpr int SLAB = 256;  // rows of the panel per workgroup
+constexpr int SLAB = 256;  // threads of a panel workgroup = rows of the panel per workgroup and row-per-thread
+constexpr int PANEL_MAX_WGS = 256;  // workgroups of one panel launch with one row per thread (beyond: two rows)
 
 // f(integral_constant<0>), f(integral_constant<1>), ... f(integral_constant<PB - 1>): a loop the compiler cannot refuse to unroll
 template <int C, typename F>
@@ -77,34 +78,59 @@ __device__ inline void st_slot(slot_t* p, double v, unsigned long long tag) {
     x[1] = __longlong_as_double((long long)tag);
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
 }
-// poll up to four slots until each carries `tag` (slots whose `need` flag is false are not waited for)
+// poll up to four slots until each carries `tag` (slots whose `need` flag is false are not waited for).  NL = how many
+// of the four can be needed at all: the others are not even loaded -- every poll of every lane is a device-coherent
+// load that travels to the memory side, and a batch of factorisations polls from hundreds of workgroups at once.
+// `nap`: s_sleep units between two polls (1 for a single factorisation: latency is everything; more in a batch).
+template <int NL>
 __device__ inline void ld_slots4(const slot_t* p0, const slot_t* p1, const slot_t* p2, const slot_t* p3, bool n0, bool n1,
-                                 bool n2, bool n3, unsigned long long tag, double& a, double& b, double& c, double& d) {
+                                 bool n2, bool n3, unsigned long long tag, int nap, double& a, double& b, double& c, double& d) {
     const double want = __longlong_as_double((long long)tag);
     for (int spin = 0; spin < (1 << 22); ++spin) {  // bounded: a lost hand-off must not hang the GPU
         slot_t x0, x1, x2, x3;
-        asm volatile(
-            "global_load_dwordx4 %0, %4, off sc1\n\t"
-            "global_load_dwordx4 %1, %5, off sc1\n\t"
-            "global_load_dwordx4 %2, %6, off sc1\n\t"
-            "global_load_dwordx4 %3, %7, off sc1\n\t"
-            "s_waitcnt vmcnt(0)"
-            : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
-            : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
-            : "memory");
+        if constexpr (NL == 1) {
+            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x0) : "v"(p0) : "memory");
+            x1 = x2 = x3 = x0;
+        } else if constexpr (NL == 2) {
+            asm volatile(
+                "global_load_dwordx4 %0, %2, off sc1\n\t"
+                "global_load_dwordx4 %1, %3, off sc1\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(x0), "=&v"(x1)
+                : "v"(p0), "v"(p1)
+                : "memory");
+            x2 = x3 = x0;
+        } else {
+            asm volatile(
+                "global_load_dwordx4 %0, %4, off sc1\n\t"
+                "global_load_dwordx4 %1, %5, off sc1\n\t"
+                "global_load_dwordx4 %2, %6, off sc1\n\t"
+                "global_load_dwordx4 %3, %7, off sc1\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
+                : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+                : "memory");
+        }
         a = x0[0];
         b = x1[0];
         c = x2[0];
         d = x3[0];
         const bool ok = (!n0 || __double_as_longlong(x0[1]) == __double_as_longlong(want)) &&
-                        (!n1 || __double_as_longlong(x1[1]) == __double_as_longlong(want)) &&
-                        (!n2 || __double_as_longlong(x2[1]) == __double_as_longlong(want)) &&
-                        (!n3 || __double_as_longlong(x3[1]) == __double_as_longlong(want));
+                        (NL < 2 || !n1 || __double_as_longlong(x1[1]) == __double_as_longlong(want)) &&
+                        (NL < 3 || !n2 || __double_as_longlong(x2[1]) == __double_as_longlong(want)) &&
+                        (NL < 3 || !n3 || __double_as_longlong(x3[1]) == __double_as_longlong(want));
         if (ok) return;
-        __builtin_amdgcn_s_sleep(1);
+        if (nap <= 1)
+            __builtin_amdgcn_s_sleep(1);
+        else
+            __builtin_amdgcn_s_sleep(8);
     }
 }
 
+// RPT = rows per thread: a slab is SLAB * RPT rows (thread t holds rows t, t + SLAB, ... of it).  1 for a single matrix
+// (shortest column step); 2 when a batch would otherwise ask for more workgroups than half the chip holds -- every
+// workgroup of a launch has to be resident, and two batches on two streams must be able to be so side by side.
+template <int RPT>
 __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double* W, int64_t ldw, double* Tjj, int64_t ldt,
                                                          double* Rjj, int64_t ldr, slot_t* part /* [2][G][PB] */,
                                                          slot_t* rowbuf /* [2][PB] */, unsigned long long tag0,
@@ -125,14 +151,22 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
     __shared__ double cols[PB * CLD];
     const int tid = threadIdx.x;
     const int G = gridDim.x;
-    const int r = blockIdx.x * SLAB + tid;
-    const bool live = r < mp;
-    // The panel's rows may be two segments of the matrix (two stacked triangles: the pb pivot rows, then the leading
-    // rows of the lower block): row r of the panel is row r (r < split) or r + gap of W.
-    const int64_t wrow = (int64_t)r + (r >= split ? gap : 0);
-    double pk[PB], acc[PB];
+    const int nap = gridDim.y > 1 ? 8 : 1;   // polling interval: a batch trades a little latency for far fewer coherent loads
+    // thread's rows: r[0] < r[1] < ...; only r[0] can be a pivot row (r[i] >= SLAB > PB for i >= 1)
+    int r[RPT];
+    bool live[RPT];
+    int64_t wrow[RPT];
+    double pk[RPT][PB], acc[PB];
 #pragma unroll
-    for (int k = 0; k < PB; ++k) pk[k] = (live && k < pb) ? W[wrow * ldw + k] : 0.0;
+    for (int i = 0; i < RPT; ++i) {
+        r[i] = (blockIdx.x * RPT + i) * SLAB + tid;
+        live[i] = r[i] < mp;
+        // The panel's rows may be two segments of the matrix (two stacked triangles: the pb pivot rows, then the leading
+        // rows of the lower block): row r of the panel is row r (r < split) or r + gap of W.
+        wrow[i] = (int64_t)r[i] + (r[i] >= split ? gap : 0);
+#pragma unroll
+        for (int k = 0; k < PB; ++k) pk[i][k] = (live[i] && k < pb) ? W[wrow[i] * ldw + k] : 0.0;
+    }
     if (blockIdx.x == 0)
         for (int i = tid; i < PB * TLD; i += SLAB) Tl[i] = 0.0;
     if (tid < 2 * PB) {  // entries beyond pb stay zero for the whole kernel (the first publish has the barrier)
@@ -161,12 +195,15 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
     };
 
     {
-        const double x = (live && r > 0) ? pk[0] : 0.0;
 #pragma unroll
-        for (int k = 0; k < PB; ++k) acc[k] = x * pk[k];
-        if (r == 0) {
+        for (int i = 0; i < RPT; ++i) {
+            const double x = (live[i] && r[i] > 0) ? pk[i][0] : 0.0;
 #pragma unroll
-            for (int k = 0; k < PB; ++k) st_slot(rowbuf + k, pk[k], tag0);
+            for (int k = 0; k < PB; ++k) acc[k] = (i == 0) ? x * pk[i][k] : fma(x, pk[i][k], acc[k]);
+        }
+        if (r[0] == 0) {
+#pragma unroll
+            for (int k = 0; k < PB; ++k) st_slot(rowbuf + k, pk[0][k], tag0);
         }
         publish(0);
     }
@@ -194,7 +231,7 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
                 const int kk = tid - (SLAB - PB);
                 if (kk < pb) {
                     double u0, u1, u2, u3;
-                    ld_slots4(rin + kk, rin + kk, rin + kk, rin + kk, true, false, false, false, tag, u0, u1, u2, u3);
+                    ld_slots4<1>(rin + kk, rin + kk, rin + kk, rin + kk, true, false, false, false, tag, nap, u0, u1, u2, u3);
                     d[kk] = u0;
                 }
             }
@@ -203,9 +240,14 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
                     const int g0 = gb + sub, g1 = g0 + 8, g2 = g0 + 16, g3 = g0 + 24;
                     const slot_t* base = pin + k;
                     double u0, u1, u2, u3;
-                    ld_slots4(base + (size_t)(g0 < G ? g0 : 0) * PB, base + (size_t)(g1 < G ? g1 : 0) * PB,
-                              base + (size_t)(g2 < G ? g2 : 0) * PB, base + (size_t)(g3 < G ? g3 : 0) * PB, g0 < G, g1 < G,
-                              g2 < G, g3 < G, tag, u0, u1, u2, u3);
+                    const slot_t *s0 = base + (size_t)(g0 < G ? g0 : 0) * PB, *s1 = base + (size_t)(g1 < G ? g1 : 0) * PB,
+                                 *s2 = base + (size_t)(g2 < G ? g2 : 0) * PB, *s3 = base + (size_t)(g3 < G ? g3 : 0) * PB;
+                    if (G <= 8)         // (uniform over the launch) only the loads that can matter are issued
+                        ld_slots4<1>(s0, s1, s2, s3, g0 < G, false, false, false, tag, nap, u0, u1, u2, u3);
+                    else if (G <= 16)
+                        ld_slots4<2>(s0, s1, s2, s3, g0 < G, g1 < G, false, false, tag, nap, u0, u1, u2, u3);
+                    else
+                        ld_slots4<4>(s0, s1, s2, s3, g0 < G, g1 < G, g2 < G, g3 < G, tag, nap, u0, u1, u2, u3);
                     t0 += (g0 < G) ? u0 : 0.0;
                     t1 += (g1 < G) ? u1 : 0.0;
                     t2 += (g2 < G) ? u2 : 0.0;
@@ -236,30 +278,36 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
         QR_STAMP(1, tq)   // scalar part: norm, tau
         // z_k = d_k + scale * q_k (the pivot row entry plus the scaled column sum) is formed where it is used
 
-        if (live && r >= c) {
-            const double v = (r == c) ? 1.0 : pk[c] * scale;
-            const double tv = -tau * v;
-            // z_k = d_k + scale q_k for the columns to the right, fetched in one batch (q, d are zero beyond pb, and
-            // so are the padded columns of the row: no per-column bounds checks, which would serialise the LDS reads)
-            double z[PB];
+        // z_k = d_k + scale q_k for the columns to the right, fetched in one batch (q, d are zero beyond pb, and so are
+        // the padded columns of the rows: no per-column bounds checks, which would serialise the LDS reads)
+        double z[PB];
 #pragma unroll
-            for (int k = c + 1; k < PB; ++k) z[k] = fma(scale, q[k], d[k]);
+        for (int k = c + 1; k < PB; ++k) z[k] = fma(scale, q[k], d[k]);
 #pragma unroll
-            for (int k = c + 1; k < PB; ++k) pk[k] = fma(z[k], tv, pk[k]);
-            pk[c] = v;
-            if (c + 1 < PB && r == c + 1) {  // the next pivot row (a lane of wave 0 in slab 0) goes out through LDS ...
+        for (int i = 0; i < RPT; ++i) {
+            if (live[i] && r[i] >= c) {
+                const double v = (i == 0 && r[0] == c) ? 1.0 : pk[i][c] * scale;
+                const double tv = -tau * v;
 #pragma unroll
-                for (int k = 0; k < PB; ++k) rowl[k] = pk[k];
+                for (int k = c + 1; k < PB; ++k) pk[i][k] = fma(z[k], tv, pk[i][k]);
+                pk[i][c] = v;
             }
+        }
+        if (c + 1 < PB && live[0] && r[0] == c + 1) {  // the next pivot row (a lane of wave 0 in slab 0) goes out through LDS ...
+#pragma unroll
+            for (int k = 0; k < PB; ++k) rowl[k] = pk[0][k];
         }
         if (c + 1 < PB) {
             // products of the next column with every column, for the rows below the next pivot (0 elsewhere: rows above
             // hold finished R entries, rows outside the matrix hold zeros)
-            const double xn = (live && r > c + 1) ? pk[c + 1 < PB ? c + 1 : c] : 0.0;
 #pragma unroll
-            for (int k = 0; k < PB; ++k) acc[k] = xn * pk[k];
+            for (int i = 0; i < RPT; ++i) {
+                const double xn = (live[i] && r[i] > c + 1) ? pk[i][c + 1 < PB ? c + 1 : c] : 0.0;
+#pragma unroll
+                for (int k = 0; k < PB; ++k) acc[k] = (i == 0) ? xn * pk[i][k] : fma(xn, pk[i][k], acc[k]);
+            }
         }
-        if (live && r == c) pk[c] = beta;  // the diagonal entry of R replaces the implicit 1 of v once the sums are formed
+        if (live[0] && r[0] == c) pk[0][c] = beta;  // the diagonal entry of R replaces the implicit 1 of v once the sums are formed
         if (c + 1 < pb && blockIdx.x == 0 && tid < PB) {
             // ... so that 32 lanes of the same wave store one slot each (LDS is in order within a wave: no barrier)
             slot_t* rout = rowbuf + (size_t)((c + 1) & 1) * PB;
@@ -292,12 +340,15 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
         for (int i = 0; i < 4; ++i) qr_stamps[i] += qr_acc[i];
 #endif
 
-    if (live) {
 #pragma unroll
-        for (int k = 0; k < PB; ++k) {
-            if (k < pb) {
-                W[wrow * ldw + k] = (r > k) ? pk[k] : (r == k ? 1.0 : 0.0);
-                if (r < pb) Rjj[(int64_t)r * ldr + k] = (r <= k) ? pk[k] : 0.0;
+    for (int i = 0; i < RPT; ++i) {
+        if (live[i]) {
+#pragma unroll
+            for (int k = 0; k < PB; ++k) {
+                if (k < pb) {
+                    W[wrow[i] * ldw + k] = (r[i] > k) ? pk[i][k] : (r[i] == k ? 1.0 : 0.0);
+                    if (i == 0 && r[0] < pb) Rjj[(int64_t)r[0] * ldr + k] = (r[0] <= k) ? pk[0][k] : 0.0;
+                }
             }
         }
     }
@@ -329,6 +380,9 @@ struct QrWorkspace {
     double* XnA;     // PB x 2 OB   near update temporaries
     double* XnB;     // PB x 2 OB
     double* XnS;     // 32 x PB x 2 OB  split-K partials of the near updates
+    double* YnA;     // the same three for the next block's near updates, which run beside the own block's on another stream
+    double* YnB;
+    double* YnS;
     int64_t sX, sG, sTmp, sGb, sPart, sRow, sXn, sXnS;
 };
 
@@ -360,12 +414,15 @@ QrWorkspace carve(void* ws, int64_t m, int64_t n, int count) {
     q.XnA = take(q.sXn);
     q.XnB = take(q.sXn);
     q.XnS = take(q.sXnS);
+    q.YnA = take(q.sXn);
+    q.YnB = take(q.sXn);
+    q.YnS = take(q.sXnS);
     return q;
 }
 
 size_t square_workspace_doubles(int64_t m, int64_t n) {
     const QrWorkspace q = carve(nullptr, m, n, 0);   // count 0: only the strides are of interest
-    return (size_t)(2 * q.sX + q.sG + q.sTmp + q.sGb + q.sPart + q.sRow + 2 * q.sXn + q.sXnS);
+    return (size_t)(2 * q.sX + q.sG + q.sTmp + q.sGb + q.sPart + q.sRow + 4 * q.sXn + 2 * q.sXnS);
 }
 
 inline GemmOpts batched(const Batch& b, int64_t sa, int64_t sb, int64_t sc, int64_t sd) {
@@ -596,28 +653,53 @@ int geqrt_core(const Batch& b, int64_t m, int64_t n, bool tri, double* V, int64_
         NPW_HIP_CHECK(hipEventRecord(side->join, s));  // so that the closing wait is valid for a single block
     }
     // Two levels of blocking.  The panel chain (latency-bound: one small persistent launch per PB columns) runs on the
-    // caller's stream and keeps only the columns it needs soon up to date -- the rest of its own OB-wide block and the
-    // whole next block ("near" columns, PB-wide reflectors, three small GEMMs per panel).  Everything further right
-    // ("far") is updated once per OB columns on the side stream with the block reflector (V_b, T_b): k = OB GEMMs that
-    // read and write the big trailing matrix OB/PB times less often than per-panel updates would.
+    // caller's stream and keeps only the rest of its OWN OB-wide block up to date (PB-wide reflectors, three small
+    // launches per panel).  The NEXT block's columns get the same per-panel updates on a second helper stream, beside the
+    // chain instead of inside it: the next panel does not read them, only the next block's first panel does (one wait
+    // per block).  Everything further right ("far") is updated once per OB columns on the first helper stream with the
+    // block reflector (V_b, T_b): k = OB GEMMs that read and write the big trailing matrix OB/PB times less often than
+    // per-panel updates would.
     for (int64_t b0 = 0; b0 < n; b0 += OB) {
         const int64_t ob = (n - b0 < OB) ? n - b0 : OB;
-        const int64_t near_end = (b0 + ob + OB < n) ? b0 + ob + OB : n;  // end of the next block
-        for (int64_t j0 = b0; j0 < b0 + ob; j0 += PB) {
-            const int64_t pb = (b0 + ob - j0 < PB) ? b0 + ob - j0 : PB;
+        const int64_t own_end = b0 + ob;
+        const int64_t near_end = (own_end + OB < n) ? own_end + OB : n;  // end of the next block
+        // A batch runs the next block's near updates on the second helper stream (measured on 4096^2 tiles: x32 122.0 ->
+        // 116.7 ms per batch, x16 67.0 -> 66.0); a single factorisation keeps them in the chain's own launches -- its
+        // three near-update kernels are latency-bound whatever their width, and the extra event per panel costs more than
+        // the narrower update saves (20.0 -> 21.0 ms).
+        const bool split_near = b.count >= 8;
+        const int64_t nnext = split_near ? near_end - own_end : 0;
+        const int64_t chain_end = split_near ? own_end : near_end;   // columns the chain's own near update covers
+        // the next block's columns were last written by the far update of the previous block (its "part 0")
+        // (a single factorisation waits on its own stream, after the block's first panel kernel: one panel time of slack)
+        if (split_near && b0 > 0 && nnext > 0) NPW_HIP_CHECK(hipStreamWaitEvent(side->stream2, side->join, 0));
+        for (int64_t j0 = b0; j0 < own_end; j0 += PB) {
+            const int64_t pb = (own_end - j0 < PB) ? own_end - j0 : PB;
             const int64_t mp = tri ? pb + (j0 + pb) : m - j0;   // tri: pivot rows + the leading rows of the lower block
             double* Wp = V + j0 * ldv + j0;
-            const int G = (int)ceil_div(mp, SLAB);
-            hipLaunchKernelGGL(qr_panel3_kernel, dim3(G, b.count), dim3(SLAB), 0, s, (int)mp, (int)pb, Wp, ldv,
+            // every workgroup of the launch has to be resident: beyond a quarter of the chip's slots per launch (two
+            // workgroups fit a CU, two batches may run side by side on two streams of the executor, the far updates' GEMM
+            // workgroups hold slots as well) a slab takes two rows per thread
+            const int rpt = (b.count * ceil_div(mp, SLAB) > PANEL_MAX_WGS) ? 2 : 1;
+            const int G = (int)ceil_div(mp, SLAB * rpt);
+            hipLaunchKernelGGL(rpt == 2 ? qr_panel3_kernel<2> : qr_panel3_kernel<1>, dim3(G, b.count), dim3(SLAB), 0, s, (int)mp, (int)pb, Wp, ldv,
                                T + j0 * ldt + j0, ldt, R + j0 * ldr + j0, ldr, reinterpret_cast<slot_t*>(q.Part),
                                reinterpret_cast<slot_t*>(q.RowBuf), call_tag + (unsigned long long)(j0 / PB) * 64, b.sV, b.sT,
                                b.sR, q.sPart / 2, q.sRow / 2, tri ? (int)pb : (int)mp, tri ? n - j0 - pb : (int64_t)0);
             NPW_LAUNCH_CHECK();
-            const int64_t nc = near_end - j0 - pb;
+            if (nnext > 0) {
+                NPW_HIP_CHECK(hipEventRecord(side->fork2, s));
+                NPW_HIP_CHECK(hipStreamWaitEvent(side->stream2, side->fork2, 0));
+                int rc = tri ? apply_tri(b, Vlow + j0, ldv, j0 + pb, pb, T + j0 * ldt + j0, ldt, V + j0 * ldv + own_end,
+                                         Vlow + own_end, nnext, q.YnA, q.sXn, q.YnB, q.sXn, q.YnS, (size_t)q.sXnS,
+                                         R + j0 * ldr + own_end, ldr, side->stream2)
+                             : apply_panel(b, Wp, ldv, mp, pb, T + j0 * ldt + j0, ldt, V + j0 * ldv + own_end, nnext, q.YnA, q.sXn,
+                                           q.YnB, q.sXn, q.YnS, (size_t)q.sXnS, nullptr, ldr, side->stream2);   // R rows: moved per block, below
+                if (rc) return rc;
+            }
+            const int64_t nc = chain_end - j0 - pb;
             if (nc > 0) {
-                // the next block's columns were last written by the side stream (far update of the previous block):
-                // waiting here, not before the panel kernel, gives that update one panel time of slack
-                if (j0 == b0 && b0 > 0 && near_end > b0 + ob) NPW_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
+                if (!split_near && j0 == b0 && b0 > 0 && near_end > own_end) NPW_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
                 int rc = tri ? apply_tri(b, Vlow + j0, ldv, j0 + pb, pb, T + j0 * ldt + j0, ldt, Wp + pb, Vlow + j0 + pb, nc, q.XnA,
                                          q.sXn, q.XnB, q.sXn, q.XnS, (size_t)q.sXnS, R + j0 * ldr + j0 + pb, ldr, s)
                              : apply_panel(b, Wp, ldv, mp, pb, T + j0 * ldt + j0, ldt, Wp + pb, nc, q.XnA, q.sXn, q.XnB, q.sXn,
@@ -625,11 +707,16 @@ int geqrt_core(const Batch& b, int64_t m, int64_t n, bool tri, double* V, int64_
                 if (rc) return rc;
             }
         }
+        if (nnext > 0) {
+            // the next block's first panel (and this block's row move and far update) start from the updated columns
+            NPW_HIP_CHECK(hipEventRecord(side->join2, side->stream2));
+            NPW_HIP_CHECK(hipStreamWaitEvent(s, side->join2, 0));
+        }
         const int64_t nfar = n - near_end;
         const bool move_near = !tri && near_end - b0 > PB;   // the dense near updates left R rows behind
         if (ob > PB || nfar > 0 || move_near) {
             // block reflector on the side stream: T_b from the Gram matrix of the block's columns, then the far update
-            NPW_HIP_CHECK(hipEventRecord(side->fork, s));
+            NPW_HIP_CHECK(hipEventRecord(side->fork, s));   // (behind the wait for join2: covers the second helper stream too)
             NPW_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
             if (move_near) {
                 const int64_t cw = near_end - b0;

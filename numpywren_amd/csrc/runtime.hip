@@ -35,6 +35,9 @@ int side_stream(hipStream_t main, SideStream** out) {
         NPW_HIP_CHECK(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
         NPW_HIP_CHECK(hipEventCreateWithFlags(&e.fork, hipEventDisableTiming));
         NPW_HIP_CHECK(hipEventCreateWithFlags(&e.join, hipEventDisableTiming));
+        NPW_HIP_CHECK(hipStreamCreateWithFlags(&e.stream2, hipStreamNonBlocking));
+        NPW_HIP_CHECK(hipEventCreateWithFlags(&e.fork2, hipEventDisableTiming));
+        NPW_HIP_CHECK(hipEventCreateWithFlags(&e.join2, hipEventDisableTiming));
     }
     *out = &e;
     return NPW_OK;

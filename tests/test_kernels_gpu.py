@@ -239,7 +239,8 @@ def test_qr_factor_wide_vs_oracle(m, n):
         np.testing.assert_allclose(got, ref, atol=tol * 10)
 
 
-@pytest.mark.parametrize("m,n,count", [(64, 64, 2), (200, 67, 5), (256, 128, 3), (512, 300, 4), (1024, 512, 9)])
+@pytest.mark.parametrize("m,n,count", [(64, 64, 2), (200, 67, 5), (256, 128, 3), (512, 300, 4), (1024, 512, 9),
+                                       (2100, 96, 36)])     # 36 x 9 slabs > 256 workgroups: two rows per thread
 def test_qr_batched_equals_one_by_one(m, n, count):
     """npw_dgeqrt_batched: `count` factorisations in lock step give what npw_dgeqrt gives for each (the same kernels
     on the same data; only the split-k of the long reductions may regroup sums when the batch changes their grid)."""
@@ -271,7 +272,8 @@ def test_qr_batched_equals_one_by_one(m, n, count):
     assert mixed[0][0].shape == (m, n) and mixed[1][0].shape == (m + 8, n)
 
 
-@pytest.mark.parametrize("n,count", [(8, 1), (32, 2), (40, 3), (96, 1), (128, 4), (200, 2), (512, 3), (1024, 2)])
+@pytest.mark.parametrize("n,count", [(8, 1), (32, 2), (40, 3), (96, 1), (128, 4), (200, 2), (512, 3), (1024, 2),
+                                     (512, 60)])     # 60 x 5 slabs > 256 workgroups: the panel kernel's two-rows-per-thread form
 def test_stacked_triangle_qr_equals_dense(n, count):
     """npw_dtpqrt_batched (the node of a TSQR tree: two stacked R factors) against the dense factorisation of the same
     stack and against the oracle: same V = [I; V2], T, R."""
