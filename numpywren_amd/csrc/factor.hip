@@ -1319,28 +1319,6 @@ int trsm_rec(const TrsmCtx& c, int64_t coff, int64_t n, bool touched) {
 // (npw_stream_create_masked -- the executor's chain stream, which runs a tile's factorisation beside the trailing
 // updates of the previous step).  The panel chain's workgroups spin on messages from one another, so every launch of
 // the factorisation must fit the stream's CUs at one workgroup (150 KiB of LDS) per CU.
-int stream_cu_count(hipStream_t s) {
-    static const int device_cus = [] {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }();
-    int cus = device_cus;
-    uint32_t mask[16] = {0};
-    const int words = (device_cus + 31) / 32;
-    if (s != nullptr && words <= 16) {
-        if (hipExtStreamGetCUMask(s, (uint32_t)words, mask) == hipSuccess) {
-            int bits = 0;
-            for (int w = 0; w < words; ++w) bits += __builtin_popcount(mask[w]);
-            if (bits > 0 && bits < cus) cus = bits;
-        } else {
-            (void)hipGetLastError();
-        }
-    }
-    return cus;
-}
-
 inline int64_t potrf_resident_wgs(int64_t n) { return n <= NB ? 1 : 1 + ceil_div(n - NB, (int64_t)PGROWS); }
 
 // Right-looking blocked Cholesky with NB-wide panels: three launches per block column

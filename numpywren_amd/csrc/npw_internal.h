@@ -92,4 +92,9 @@ struct SideStream {
 };
 int side_stream(hipStream_t main, SideStream** out);
 
+// Compute units a launch on `s` can be resident on: the device's, or fewer for a stream created with a CU mask
+// (npw_stream_create_masked: the executor's chain partition).
+int stream_cu_count(hipStream_t s);
+int device_cu_count();
+
 }  // namespace npw

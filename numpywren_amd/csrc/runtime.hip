@@ -28,6 +28,8 @@ using npw::as_stream;
 #include <unordered_map>
 
 namespace npw {
+int stream_cu_count_query(hipStream_t s);
+
 int side_stream(hipStream_t main, SideStream** out) {
     static thread_local std::unordered_map<hipStream_t, SideStream> table;
     SideStream& e = table[main];
@@ -42,6 +44,44 @@ int side_stream(hipStream_t main, SideStream** out) {
     *out = &e;
     return NPW_OK;
 }
+
+int stream_cu_count(hipStream_t s) {
+    // (cached per stream and host thread: the mask of a stream never changes, the query is a driver call)
+    static thread_local std::unordered_map<hipStream_t, int> cache;
+    auto it = cache.find(s);
+    if (it != cache.end()) return it->second;
+    const int result = stream_cu_count_query(s);
+    cache[s] = result;
+    return result;
+}
+
+int device_cu_count() {
+    static const int device_cus = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }();
+    return device_cus;
+}
+
+int stream_cu_count_query(hipStream_t s) {
+    const int device_cus = device_cu_count();
+    int cus = device_cus;
+    uint32_t mask[16] = {0};
+    const int words = (device_cus + 31) / 32;
+    if (s != nullptr && words <= 16) {
+        if (hipExtStreamGetCUMask(s, (uint32_t)words, mask) == hipSuccess) {
+            int bits = 0;
+            for (int w = 0; w < words; ++w) bits += __builtin_popcount(mask[w]);
+            if (bits > 0 && bits < cus) cus = bits;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    return cus;
+}
+
 }  // namespace npw
 
 extern "C" {
