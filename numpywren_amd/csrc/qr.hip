@@ -646,6 +646,17 @@ int geqrt_core(const Batch& b, int64_t m, int64_t n, bool tri, double* V, int64_
     static std::atomic<unsigned long long> call_counter{
         (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() & 0x3fffffffULL};
     const unsigned long long call_tag = (call_counter.fetch_add(1) + 1) << 24;
+    // T's off-diagonal blocks: block column by block column during the factorisation, behind the far updates on the helper
+    // stream, or from the Gram matrix of all reflectors afterwards (the round-2 form).  Measured on 4096^2 tiles
+    // (gpurun_out/r03p, r03q): dense x1 20.09 -> 17.84 ms, x8 40.3 -> 37.4, x16 65.4 -> 63.5, x32 117.2 -> 116.8; stacked
+    // triangles x1 19.6 -> 18.8, x4 26.5 -> 25.0, x8 35.6 -> 35.7, x16 52.0 -> 56.6, x32 89.8 -> 100.4 -- their far updates
+    // are a third of the dense ones, a big batch keeps the helper stream busy already and the extra work delays the
+    // updates the panel chain waits for.  NPW_QR_T_PROGRESSIVE=0 / 1 forces either form (A/B runs).
+    static const int t_mode = [] {
+        const char* e = getenv("NPW_QR_T_PROGRESSIVE");
+        return e == nullptr ? -1 : (atoi(e) != 0 ? 1 : 0);
+    }();
+    const bool progressive_t = t_mode >= 0 ? t_mode == 1 : (!tri || b.count < 8);
     SideStream* side = nullptr;
     {
         int rc = side_stream(s, &side);
@@ -714,7 +725,7 @@ int geqrt_core(const Batch& b, int64_t m, int64_t n, bool tri, double* V, int64_
         }
         const int64_t nfar = n - near_end;
         const bool move_near = !tri && near_end - b0 > PB;   // the dense near updates left R rows behind
-        if (ob > PB || nfar > 0 || move_near) {
+        if (ob > PB || nfar > 0 || move_near || (progressive_t && b0 > 0)) {
             // block reflector on the side stream: T_b from the Gram matrix of the block's columns, then the far update
             NPW_HIP_CHECK(hipEventRecord(side->fork, s));   // (behind the wait for join2: covers the second helper stream too)
             NPW_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
@@ -758,11 +769,40 @@ int geqrt_core(const Batch& b, int64_t m, int64_t n, bool tri, double* V, int64_
                 if (part == 0) NPW_HIP_CHECK(hipEventRecord(side->join, side->stream));
             }
             if (nfar <= 0) NPW_HIP_CHECK(hipEventRecord(side->join, side->stream));
+            if (progressive_t && b0 > 0) {
+                // T's block column of this block, above its diagonal block, DLARFT-style:
+                //   T[0:b0, b] = -T[0:b0, 0:b0] * (V[:, 0:b0]^T V_b) * T_b
+                // behind the far update on the helper stream -- nobody waits for it before the factorisation ends, and the
+                // panel chain leaves most of the chip idle; the same flops as the Gram matrix + bottom-up merges that
+                // used to follow the factorisation with the chip to themselves (x32: 30.7 of 116.7 ms).
+                double* Tcol = T + b0;               // rows 0 .. b0, columns b0 .. b0 + ob
+                GemmOpts g1 = batched(b, b.sV, b.sV, 0, q.sX);
+                const int64_t kk = tri ? b0 : mb;    // tri: V2 is upper triangular, columns < b0 end at row b0
+                const double* Aop = tri ? Vlow : V + b0 * ldv;
+                const double* Bop = tri ? Vlow + b0 : Vb;
+                int64_t want = 512 / ((ceil_div(b0, 64) * ceil_div(ob, 64) * b.count) > 0 ? (ceil_div(b0, 64) * ceil_div(ob, 64) * b.count) : 1);
+                if (want > kk / 256) want = kk / 256;
+                if (want > 32) want = 32;
+                if (want > 1 && (size_t)want * b0 * ob <= (size_t)q.sG) {
+                    g1.splitk = (int)want;
+                    g1.splitk_ws = q.G;
+                }
+                int rc = gemm<double>('T', 'N', b0, ob, kk, 1.0, Aop, ldv, Bop, ldv, 0.0, nullptr, 0, q.X1, ob, g1, side->stream);
+                if (rc) return rc;
+                GemmOpts g2 = batched(b, q.sX, b.sT, 0, q.sX);
+                rc = gemm<double>('N', 'N', b0, ob, ob, 1.0, q.X1, ob, T + b0 * ldt + b0, ldt, 0.0, nullptr, 0, q.X2, ob, g2,
+                                  side->stream);
+                if (rc) return rc;
+                GemmOpts g3 = batched(b, b.sT, q.sX, 0, b.sT);
+                g3.a_upper_tri = true;
+                rc = gemm<double>('N', 'N', b0, ob, b0, -1.0, T, ldt, q.X2, ob, 0.0, nullptr, 0, Tcol, ldt, g3, side->stream);
+                if (rc) return rc;
+            }
         }
     }
     NPW_HIP_CHECK(hipEventRecord(side->join, side->stream));  // everything the side stream still has in flight
     NPW_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
-    if (n > OB) {
+    if (n > OB && !progressive_t) {
         // G = V^T V, then the off-diagonal OB-blocks of T bottom-up (the diagonal ones are final)
         // (lower triangle only, and V is lower trapezoidal: tile (i0, j0) sums over the rows from max(i0, j0) on --
         //  a sixth of the full product for a square matrix)
