@@ -38,8 +38,8 @@ TILE = 4096
 NORTH_STAR_1GPU_TFLOPS = 70.27
 NORTH_STAR_1GPU_SOURCE = "gpurun_out/r03a/bench.json north_star (driver BENCH_r02.json: 70.0)"
 PREDICTED_STRONG_SCALING = {"1": 70.3, "2": 133, "4": 247, "8": 420}
-SYRK_TRAFFIC_BYTES = 3.78e9    # PMC passes of a separate run (2 x FETCH_SIZE + WRITE_SIZE per one-tile launch of the tagged kernel)
-SYRK_TRAFFIC_SOURCE = "profiles/r02_bench_pmc_final.json (rocprofv3 --pmc, separate passes)"
+SYRK_TRAFFIC_BYTES = 2.27e9    # PMC passes of a separate run of this command ((2 x FETCH_SIZE + WRITE_SIZE) per tile update of the tagged kernel)
+SYRK_TRAFFIC_SOURCE = "profiles/r03_bench_pmc.json (rocprofv3 --pmc, separate passes; 1.88e9 - 2.27e9 between boxes, floor of the tile map 1.35e9)"
 
 
 def build_input(be, nb, b, key, rank=0, world=1, owner=None):
