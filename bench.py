@@ -37,7 +37,9 @@ TILE = 4096
 # measured kernel times (never a measured value: no multi-GPU node has been available to the builder)
 NORTH_STAR_1GPU_TFLOPS = 70.27
 NORTH_STAR_1GPU_SOURCE = "gpurun_out/r03a/bench.json north_star (driver BENCH_r02.json: 70.0)"
-PREDICTED_STRONG_SCALING = {"1": 70.3, "2": 133, "4": 247, "8": 420}
+PREDICTED_STRONG_SCALING = {"1": 69.8, "2": 137, "4": 239, "8": 432,
+                            "source": "tools/predict_scaling.py: list-scheduling simulation of dist.py with the measured kernel times, "
+                                      "40 - 64 GB/s per xGMI link and direction (N = 8: 417 - 447)"}
 SYRK_TRAFFIC_BYTES = 2.27e9    # PMC passes of a separate run of this command ((2 x FETCH_SIZE + WRITE_SIZE) per tile update of the tagged kernel)
 SYRK_TRAFFIC_SOURCE = "profiles/r03_bench_pmc.json (rocprofv3 --pmc, separate passes; 1.88e9 - 2.27e9 between boxes, floor of the tile map 1.35e9)"
 
