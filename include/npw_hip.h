@@ -286,6 +286,10 @@ int npw_daxpby(int64_t rows, int64_t cols, double alpha, const double* X, int64_
  * `.T` of BigMatrixView (reference numpywren/matrix.py:646-647,658-659).      */
 int npw_dtranspose(int64_t rows, int64_t cols, const double* A, int64_t lda, double* B,
                    int64_t ldb, npw_stream_t stream);
+/* the same for float32 tiles (the GEMM program's inputs, reference algs.py:251-266: a B tile that several products
+ * read is transposed once, so that those products run in the k-contiguous NT form)                     */
+int npw_stranspose(int64_t rows, int64_t cols, const float* A, int64_t lda, float* B, int64_t ldb,
+                   npw_stream_t stream);
 
 /* keep the lower (uplo='L') or upper ('U') triangle incl. diagonal of the rows x cols
  * matrix, zero the rest; unit_diag != 0 forces the diagonal to 1.  In place.   */

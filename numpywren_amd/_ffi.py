@@ -93,6 +93,7 @@ PROTOTYPES = {
     "npw_zero_if": (c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "npw_daxpby": (c_int, [_i64, _i64, c_double, _vp, _i64, c_double, _vp, _i64, _vp, _i64, _vp]),
     "npw_dtranspose": (c_int, [_i64, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "npw_stranspose": (c_int, [_i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     "npw_dtri_keep": (c_int, [c_char, c_int, _i64, _i64, _vp, _i64, _vp]),
     "npw_dblockdiag_rows": (c_int, [_i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     "npw_convert": (c_int, [_i64, _i64, _vp, _i64, c_int, _vp, _i64, c_int, _vp]),

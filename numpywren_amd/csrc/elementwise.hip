@@ -154,9 +154,9 @@ __global__ void axpby_kernel(int64_t rows, int64_t cols, double alpha, const dou
     }
 }
 
-__global__ void transpose_kernel(int64_t rows, int64_t cols, const double* A, int64_t lda, double* B,
-                                 int64_t ldb) {
-    __shared__ double tile[32][33];
+template <typename T>
+__global__ void transpose_kernel(int64_t rows, int64_t cols, const T* A, int64_t lda, T* B, int64_t ldb) {
+    __shared__ T tile[32][33];
     const int64_t tiles_c = (cols + 31) / 32, tiles_r = (rows + 31) / 32;
     for (int64_t t = blockIdx.x; t < tiles_r * tiles_c; t += gridDim.x) {
         const int64_t tr = t / tiles_c, tc = t - tr * tiles_c;
@@ -373,8 +373,19 @@ int npw_dtranspose(int64_t rows, int64_t cols, const double* A, int64_t lda, dou
     NPW_REQUIRE(A != nullptr && B != nullptr && lda >= cols && ldb >= rows, "npw_dtranspose: bad arguments");
     int64_t tiles = ceil_div(rows, 32) * ceil_div(cols, 32);
     int grid = (int)(tiles < 65536 ? tiles : 65536);
-    hipLaunchKernelGGL(transpose_kernel, dim3(grid), dim3(256), 0, as_stream(stream), rows, cols, A, lda,
+    hipLaunchKernelGGL(transpose_kernel<double>, dim3(grid), dim3(256), 0, as_stream(stream), rows, cols, A, lda,
                        B, ldb);
+    NPW_LAUNCH_CHECK();
+    return NPW_OK;
+}
+
+int npw_stranspose(int64_t rows, int64_t cols, const float* A, int64_t lda, float* B, int64_t ldb,
+                   npw_stream_t stream) {
+    if (rows <= 0 || cols <= 0) return NPW_OK;
+    NPW_REQUIRE(A != nullptr && B != nullptr && lda >= cols && ldb >= rows, "npw_stranspose: bad arguments");
+    int64_t tiles = ceil_div(rows, 32) * ceil_div(cols, 32);
+    int grid = (int)(tiles < 65536 ? tiles : 65536);
+    hipLaunchKernelGGL(transpose_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), rows, cols, A, lda, B, ldb);
     NPW_LAUNCH_CHECK();
     return NPW_OK;
 }

@@ -628,3 +628,32 @@ def test_trsm_in_place_through_the_abi(n, m):
     ref = oracle.trsm(Lh, Bh)
     np.testing.assert_allclose(out, ref, rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(inplace, ref, rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_gemm_reused_operand_takes_the_transposed_copy(dtype):
+    """A big k x n operand that is multiplied several times (the B tiles of the GEMM program) is transposed once on its
+    second use and the later products run in the NT form: same products in the same order -> bitwise the first call's
+    result; a rewritten tile drops the copy."""
+    be = kernels.get_backend()
+    n = be.GEMM_TRANSPOSE_MIN
+    rng = np.random.default_rng(7)
+    A = be.to_device(rng.standard_normal((256, n)).astype(dtype))
+    Bh = rng.standard_normal((n, n)).astype(dtype)
+    B = be.to_device(Bh)
+    first = be.to_host(be.gemm(A, B))
+    assert B.gemm_bt is None and B.gemm_uses == 1
+    second = be.to_host(be.gemm(A, B))
+    assert B.gemm_bt is not None and B.gemm_bt.shape == (n, n)
+    assert np.array_equal(be.to_host(B.gemm_bt), Bh.T)
+    third = be.to_host(be.gemm(A, B, alpha=1.0))
+    assert np.array_equal(first, second) and np.array_equal(first, third)
+    ref = be.to_host(A).astype(np.float64) @ Bh.astype(np.float64)
+    np.testing.assert_allclose(first, ref, rtol=1e-3 if dtype == np.float32 else 1e-12, atol=1e-2 if dtype == np.float32 else 1e-10)
+    # small operands and transposed ones are left alone
+    small = be.to_device(rng.standard_normal((n, 64)).astype(dtype))
+    be.gemm(A, small), be.gemm(A, small)
+    assert small.gemm_bt is None
+    # the tile is rewritten (here: as the output of a product): the stale copy goes
+    be.gemm(be.to_device(np.eye(n, dtype=dtype)), B.gemm_bt, False, True, out=B)
+    assert B.gemm_bt is None and B.gemm_uses == 0
