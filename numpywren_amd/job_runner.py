@@ -347,6 +347,29 @@ class LambdaPackExecutor(object):
         self.chain_runs += 1
         return out
 
+    # ---- a kernel whose workgroups wait for one another gets the device to itself ----
+    def _fence_in(self, compute, stream):
+        """With several streams: `stream` waits for the tails of the others (returned, for _fence_out).  Two kernels of
+        this kind side by side -- the Cholesky panel chain, the QR panel kernel of a batch: every workgroup of a launch
+        has to be resident -- can each hold the slots the other one is waiting for (workgroups are dealt round-robin
+        to the XCDs, so BOTH launches can be partially resident at once); the bounded spins would then time out and
+        the results would be wrong, not late."""
+        if len(self.streams) <= 1 or not getattr(compute, "_npw_needs_whole_cus", False):
+            return []
+        others = [s for s in self.streams if s is not stream]
+        for o in others:
+            ev = self.be.record_new(o)
+            self.be.wait_event(stream, ev)
+            self.be.recycle_event(ev)   # (a stream wait captures the event's state when it is enqueued)
+        return others
+
+    def _fence_out(self, others, stream):
+        if others:
+            ev = self.be.record_new(stream)
+            for o in others:
+                self.be.wait_event(o, ev)
+            self.be.recycle_event(ev)
+
     # ---- one task ----
     def run_task(self, expr_idx, var_values, stream=None):
         t_enq = time.time()
@@ -367,12 +390,7 @@ class LambdaPackExecutor(object):
         # starves next to chip-filling GEMMs of other streams -- every launch then waits for ~1 ms workgroups to
         # retire.  With several streams such a task gets the device to itself: its stream first waits for the other
         # streams' tails, and they wait for it afterwards.
-        exclusive = len(self.streams) > 1 and getattr(compute, "_npw_needs_whole_cus", False)
-        others = [s for s in self.streams if s is not stream] if exclusive else []
-        for o in others:
-            ev = self.be.record_new(o)
-            self.be.wait_event(stream, ev)
-            self.be.recycle_event(ev)   # (a stream wait captures the event's state when it is enqueued)
+        others = self._fence_in(compute, stream)
         tiles = [mats[m].get_tile(*idx, stream=stream) for m, idx in task.reads]
         read_bytes = sum(t.nbytes for t in tiles)
         if device_kernel:
@@ -384,11 +402,7 @@ class LambdaPackExecutor(object):
             host = [self.be.to_host(t, stream) for t in tiles]
             args = [host[j] if kind == "tile" else task.consts[j] for kind, j in task.arg_kinds]
             results = compute(*args, **task.kwargs)
-        if others:
-            ev = self.be.record_new(stream)
-            for o in others:
-                self.be.wait_event(o, ev)
-            self.be.recycle_event(ev)
+        self._fence_out(others, stream)
         flops_fn = getattr(compute, "flops", None)
         if flops_fn is not None:
             try:
@@ -450,8 +464,10 @@ class LambdaPackExecutor(object):
             read_bytes += sum(t.nbytes for t in tiles)
             arg_lists.append([tiles[j] if kind == "tile" else task.consts[j] for kind, j in task.arg_kinds])
             kwargs_list.append(task.kwargs)
+        others = self._fence_in(compute, stream)
         with kernels.stream_scope(stream, self.program.info_flags_sink(tasks[0]), self.exact_zero):
             results = compute._npw_batch(self.be, stream, arg_lists, kwargs_list)
+        self._fence_out(others, stream)
         flops_fn = getattr(compute, "flops", None)
         last, write_bytes = None, 0
         for task, args, res in zip(tasks, arg_lists, results):

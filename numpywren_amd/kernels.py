@@ -312,6 +312,8 @@ def _qr_factor_batch(be, stream, arg_lists, kwargs_list):
 
 
 qr_factor._npw_batch = _qr_factor_batch
+# the panel kernel's workgroups exchange partial sums: every workgroup of a launch must be resident (job_runner._fence_in)
+qr_factor._npw_needs_whole_cus = True
 
 
 def _qr_flops(*blocks):
@@ -347,6 +349,7 @@ def _lq_factor_batch(be, stream, arg_lists, kwargs_list):
 
 
 lq_factor._npw_batch = _lq_factor_batch
+lq_factor._npw_needs_whole_cus = True
 
 
 @_kernel
@@ -520,6 +523,7 @@ def _qr_factor_triangular_batch(be, stream, arg_lists, kwargs_list):
 
 
 qr_factor_triangular._npw_batch = _qr_factor_triangular_batch
+qr_factor_triangular._npw_needs_whole_cus = True
 
 
 def banded_to_bidiagonal(x):

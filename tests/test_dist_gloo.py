@@ -204,20 +204,25 @@ def _worker(rank, world, port, scenario, outdir):
         program, meta = alg_wrappers.cholesky(X)
         program.start()
         from numpywren_amd import job_runner
-        real = job_runner.LambdaPackExecutor.run_task
+        real, real_batch = job_runner.LambdaPackExecutor.run_task, job_runner.LambdaPackExecutor.run_batch
 
         def slow(self, e, v, stream=None):
             if rank == 1:
-                _time.sleep(0.01)
+                _time.sleep(0.05)
             return real(self, e, v, stream=stream)
-        job_runner.LambdaPackExecutor.run_task = slow
-        dist.TIMEOUT_CHECK_EVERY = 8
-        res = dist.lambdapack_run_distributed(program, comm, timeout=0.25)
-        job_runner.LambdaPackExecutor.run_task = real
+
+        def slow_batch(self, nodes, stream=None):
+            if rank == 1:
+                _time.sleep(0.05)
+            return real_batch(self, nodes, stream=stream)
+        job_runner.LambdaPackExecutor.run_task, job_runner.LambdaPackExecutor.run_batch = slow, slow_batch
+        dist.TIMEOUT_CHECK_EVERY = 4
+        res = dist.lambdapack_run_distributed(program, comm, timeout=0.2)      # rank 1 is past it after four of its launches
+        job_runner.LambdaPackExecutor.run_task, job_runner.LambdaPackExecutor.run_batch = real, real_batch
         steps = [None] * world
         comm.dist.all_gather_object(steps, (res["steps"], res["timed_out"]))
         assert len(set(steps)) == 1 and steps[0][1] is True, steps          # same position everywhere
-        assert 0 < res["steps"] < nb * (nb + 1) * (nb + 2) // 6
+        assert 0 < res["steps"] and len(res["executed_messages"]) < nb * (nb + 1) * (nb + 2) // 6 // 2
         assert program.program_status() == lp.PS.RUNNING
         # resume without a limit: the program completes and the factor is right
         res2 = dist.lambdapack_run_distributed(program, comm, timeout=None)
