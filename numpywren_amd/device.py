@@ -862,7 +862,7 @@ class HipBackend(object):
         # A big B operand in its k x n storage (op(B) = N) that is multiplied more than once -- the B tiles of the GEMM
         # program, each read by M products -- is transposed ONCE on its second use and the products take the NT form from
         # then on, in which both operands are k-contiguous (measured on 4096^3: fp32 132.8 -> 138.5 TFLOP/s, fp64 63.6 ->
-        # 72.0; the transposition costs ~0.05 / 0.1 ms).  Tiles are immutable, the copy lives and dies with its tile;
+        # 72.0; the transposition costs ~0.05 / 0.1 ms -- for fp64 and a big product it pays at once, with a temporary copy).  Tiles are immutable, the copy lives and dies with its tile;
         # the same products in the same order, so the result is bitwise that of the NN call.
         if not transpose_B and B is not out and min(B.shape) >= self.GEMM_TRANSPOSE_MIN:
             bt = B.gemm_bt
@@ -870,6 +870,8 @@ class HipBackend(object):
                 B.gemm_uses += 1
                 if B.gemm_uses >= 2:
                     bt = B.gemm_bt = self.transpose(B, sh)
+                elif dt == _F64 and m >= self.GEMM_TRANSPOSE_MIN:
+                    bt = self.transpose(B, sh)      # fp64: 0.1 ms buys 0.25 ms already on the first product; not kept
             if bt is not None:
                 B, transpose_B = bt, True
         self._use(sh, A, B, C, out)

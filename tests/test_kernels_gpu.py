@@ -642,7 +642,7 @@ def test_gemm_reused_operand_takes_the_transposed_copy(dtype):
     Bh = rng.standard_normal((n, n)).astype(dtype)
     B = be.to_device(Bh)
     first = be.to_host(be.gemm(A, B))
-    assert B.gemm_bt is None and B.gemm_uses == 1
+    assert B.gemm_bt is None and B.gemm_uses == 1        # (a 256-row product: no temporary copy either)
     second = be.to_host(be.gemm(A, B))
     assert B.gemm_bt is not None and B.gemm_bt.shape == (n, n)
     assert np.array_equal(be.to_host(B.gemm_bt), Bh.T)
