@@ -503,3 +503,76 @@ def test_config4_gemm32_32768(hbm_store):
     program.free()
     A.free()
     Bm.free()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Ragged problems at the real tile size: the last block row / column is 1808 wide (10000 = 2 x 4096 + 1808), which is
+# not a multiple of any tiling -- the EDGE instantiations of the GEMM kernel at scale, potrf's two-launch path
+# (1808 is not a multiple of 128), trsm's ragged tail groups, the symmetric update's fall-back to the general kernel.
+# ---------------------------------------------------------------------------------------------------------------
+def test_ragged_cholesky_10000(hbm_store):
+    be = get_backend()
+    n, nb = 10000, 3
+    edges = [0, B, 2 * B, n]
+    G = be.fill_random((n, 96), seed=77)
+    X = BigMatrix("t4096_chol_ragged", shape=(n, n), shard_sizes=(B, B), write_header=True)
+    for i in range(nb):
+        Gi = be.block(G, edges[i], edges[i + 1], 0, 96)
+        for j in range(i + 1):
+            t = be.gemm(Gi, be.block(G, edges[j], edges[j + 1], 0, 96), False, True)
+            if i == j:
+                t = be.add_diag(t, float(n))
+            X.put_tile(t, i, j)
+    program, meta = alg_wrappers.cholesky(X)
+    program.config["executor"]["reclaim_intermediates"] = True
+    _run(program)
+    assert program.program_status() == lp.PS.SUCCESS, program.exceptions
+    O = meta["outputs"][0]
+    assert O.get_tile(2, 2).shape == (1808, 1808) and O.get_tile(2, 0).shape == (1808, B)
+    import bench
+    res = bench.cholesky_residual(be, X, O, nb, full=True)
+    assert res <= 1e-12 and res < 1e-14, res
+    # the ragged diagonal tile against LAPACK on the host: A22 - L20 L20^T - L21 L21^T = L22 L22^T
+    S = X.get_tile(2, 2)
+    for k in range(2):
+        S = be.gemm(O.get_tile(2, k), O.get_tile(2, k), False, True, alpha=-1.0, beta=1.0, C=S)
+    ref = np.linalg.cholesky(be.to_host(S))
+    got = be.to_host(O.get_tile(2, 2))
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-11 * np.abs(ref).max())
+    assert not np.triu(got, 1).any()
+    program.free()
+    X.free()
+
+
+def test_ragged_gemm_program_10000_fp64(hbm_store):
+    """The GEMM program on a 3 x 3 grid of 4096 / 4096 / 1808 tiles (fp64), parity and fused modes, against the host
+    product on sampled rows of every output tile."""
+    be = get_backend()
+    n, nb = 10000, 3
+    edges = [0, B, 2 * B, n]
+    rng = np.random.default_rng(99)
+    Ah = rng.standard_normal((n, n))
+    Bh = rng.standard_normal((n, n))
+    A = BigMatrix("t4096_gA_ragged", shape=(n, n), shard_sizes=(B, B))
+    Bm = BigMatrix("t4096_gB_ragged", shape=(n, n), shard_sizes=(B, B))
+    for i in range(nb):
+        for j in range(nb):
+            A.put_tile(be.to_device(Ah[edges[i]:edges[i + 1], edges[j]:edges[j + 1]]), i, j)
+            Bm.put_tile(be.to_device(Bh[edges[i]:edges[i + 1], edges[j]:edges[j + 1]]), i, j)
+    rows = np.array([0, 1, 77, 1807])                    # valid in every block row
+    ref = {i: Ah[edges[i] + rows] @ Bh for i in range(nb)}
+    for fuse in (False, True):
+        program, meta = alg_wrappers.gemm(A, Bm)
+        program.config["executor"]["fuse_gemm_reduction"] = fuse
+        program.config["executor"]["reclaim_intermediates"] = True
+        _run(program)
+        assert program.program_status() == lp.PS.SUCCESS, program.exceptions
+        C = meta["outputs"][0]
+        for i in range(nb):
+            for j in range(nb):
+                got = be.to_host(C.get_tile(i, j))
+                assert got.shape == (edges[i + 1] - edges[i], edges[j + 1] - edges[j])
+                np.testing.assert_allclose(got[rows], ref[i][:, edges[j]:edges[j + 1]], rtol=0, atol=1e-13 * n * 4,
+                                           err_msg=f"fuse={fuse} C[{i},{j}]")
+        program.free()
+        C.free()
