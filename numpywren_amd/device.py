@@ -864,16 +864,28 @@ class HipBackend(object):
         # then on, in which both operands are k-contiguous (measured on 4096^3: fp32 132.8 -> 138.5 TFLOP/s, fp64 63.6 ->
         # 72.0; the transposition costs ~0.05 / 0.1 ms -- for fp64 and a big product it pays at once, with a temporary copy).  Tiles are immutable, the copy lives and dies with its tile;
         # the same products in the same order, so the result is bitwise that of the NN call.
-        if not transpose_B and B is not out and min(B.shape) >= self.GEMM_TRANSPOSE_MIN:
-            bt = B.gemm_bt
-            if bt is None:
-                B.gemm_uses += 1
-                if B.gemm_uses >= 2:
-                    bt = B.gemm_bt = self.transpose(B, sh)
-                elif dt == _F64 and m >= self.GEMM_TRANSPOSE_MIN:
-                    bt = self.transpose(B, sh)      # fp64: 0.1 ms buys 0.25 ms already on the first product; not kept
+        # (the same for an m x k operand read as op(A) = T: the V tiles of the QR / BDFAC programs, applied to a whole block row)
+        def fast_form(X, other_dim):
+            """The transposed copy of X to use instead of X, or None."""
+            if X is out or X is C or min(X.shape) < self.GEMM_TRANSPOSE_MIN:
+                return None
+            xt = X.gemm_bt
+            if xt is None:
+                X.gemm_uses += 1
+                if X.gemm_uses >= 2:
+                    xt = X.gemm_bt = self.transpose(X, sh)
+                elif dt == _F64 and other_dim >= self.GEMM_TRANSPOSE_MIN:
+                    xt = self.transpose(X, sh)      # fp64: 0.1 ms buys 0.25 ms already on the first product; not kept
+            return xt
+
+        if not transpose_B:
+            bt = fast_form(B, m)
             if bt is not None:
                 B, transpose_B = bt, True
+        if transpose_A:
+            at = fast_form(A, n)
+            if at is not None:
+                A, transpose_A = at, False
         self._use(sh, A, B, C, out)
         fn = self.lib.npw_dgemm if dt == _F64 else self.lib.npw_sgemm
         _ffi.check(fn(b"T" if transpose_A else b"N", b"T" if transpose_B else b"N", m, n, ka, alpha, A.ptr, A.shape[1],
