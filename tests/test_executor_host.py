@@ -307,6 +307,35 @@ def test_gemm_fused_reduction(tag, b, oracle_backend):
     assert gemms == nb ** 3 and not any(c[0] == "add_n" for c in oracle_backend.calls)
 
 
+@pytest.mark.parametrize("nb", [1, 2, 3, 4, 5, 6])
+def test_gemm_fused_reduction_every_tree_shape(nb, oracle_backend):
+    """Square grids of 1 ... 6 blocks: tree depth 0 (K = 1: no add_matrices task at all), 1 (K <= 4) and 2 (K = 5, 6:
+    a second level whose other operands are never-written constant_zeros tiles); fused == parity == A @ B."""
+    from numpywren_amd.job_runner import ReductionFusion
+    rng = np.random.default_rng(nb)
+    b = 4
+    A, B = rng.standard_normal((nb * b, nb * b)), rng.standard_normal((nb * b, nb * b))
+    outs = []
+    for fuse in (False, True):
+        Ab = BigMatrix(f"gemmt_A_{nb}_{fuse}", shape=A.shape, shard_sizes=(b, b))
+        Bb = BigMatrix(f"gemmt_B_{nb}_{fuse}", shape=B.shape, shard_sizes=(b, b))
+        shard_matrix(Ab, A)
+        shard_matrix(Bb, B)
+        program, meta = alg_wrappers.gemm(Ab, Bb)
+        program.config["executor"]["fuse_gemm_reduction"] = fuse
+        if fuse:
+            fusion = ReductionFusion(program.program)
+            if nb == 1:
+                assert fusion.roots == {}            # K = 1: the tree has no add_matrices task, nothing to fuse
+            else:
+                assert len(fusion.roots) == nb * nb and set(fusion.roots.values()) == {nb}
+        run(program)
+        assert program.program_status() == lp.PS.SUCCESS, program.exceptions
+        outs.append(meta["outputs"][0].numpy())
+    np.testing.assert_allclose(outs[0], A @ B, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(outs[1], outs[0], rtol=1e-13, atol=1e-13)
+
+
 def test_fusion_leaves_other_programs_alone(oracle_backend):
     """Nothing fuses in a program without the gemm -> add_matrices pattern; a Temp tile with a second reader would not
     fuse either (the DAG decides, not the program's name)."""
