@@ -97,6 +97,7 @@ class RcclTransport(object):
         self.stream = Stream(sh.value, True, "xgmi")
         self.rank, self.world = rank, world
         self._group = None                # open group: received tiles whose `ready` event is recorded at group end
+        self._held = []                   # ... and the tiles being sent: alive until the launch has been enqueued
 
     def begin_group(self):
         """Everything posted until end_group() leaves as ONE RCCL launch (ncclGroupStart / ncclGroupEnd): the sends and
@@ -109,7 +110,12 @@ class RcclTransport(object):
     def end_group(self):
         if self._group is not None:
             pending, self._group = self._group, None
-            _ffi.check(self.lib.npw_comm_group_end(self.handle), "npw_comm_group_end")   # the launch happens here
+            try:
+                _ffi.check(self.lib.npw_comm_group_end(self.handle), "npw_comm_group_end")   # the launch happens here
+            finally:
+                # Only now may a sent tile's last reference go: inside the group RCCL has merely noted the transfer, and a
+                # buffer released before the launch is enqueued could be recycled behind an event that does not cover it.
+                self._held = []
             for tile in pending:
                 self.be._produced(self.stream, tile)
 
@@ -117,6 +123,7 @@ class RcclTransport(object):
         be, cs = self.be, self.stream
         be._use(cs, tile)                 # after the producer; the buffer is not recycled before the send has left
         if self._group is not None:
+            self._held.append(tile)
             for d in dsts:
                 _ffi.check(self.lib.npw_send_tile(self.handle, tile.ptr, tile.nbytes, int(d), cs.handle), "npw_send_tile")
         elif len(dsts) == 1:
@@ -523,13 +530,15 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
         # the prologue is ONE grouped exchange: every link carries its input tiles at once (the GEMM program's A / B
         # panels: SUMMA's traffic as a single all-to-all-v launch instead of a queue of single transfers)
         comm.transport.begin_group()
-        for r, (home, consumers) in moves.items():
-            meta = metas.read(*r)
-            if rank == home:
-                comm.send_tile(_stored_tile(mats[r[0]], r[1]), consumers, known=meta is not None, meta=meta)
-            elif rank in consumers:
-                mats[r[0]].put_tile(comm.recv_tile(home, meta), *r[1])
-        comm.transport.end_group()
+        try:
+            for r, (home, consumers) in moves.items():
+                meta = metas.read(*r)
+                if rank == home:
+                    comm.send_tile(_stored_tile(mats[r[0]], r[1]), consumers, known=meta is not None, meta=meta)
+                elif rank in consumers:
+                    mats[r[0]].put_tile(comm.recv_tile(home, meta), *r[1])
+        finally:
+            comm.transport.end_group()          # (also on an error: a group must never stay open)
         step, timed_out = 0, False
         while program.program_status() == lp.PS.RUNNING and not program.all_terminators_done():
             node = program.dequeue()
@@ -569,20 +578,22 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
             # push the outputs to the remote consumers: both sides evaluate the same static plan here; the transfers of
             # one group of tasks (the right-hand sides of a batched solve, the nodes of a tree level) are one launch
             comm.transport.begin_group()
-            for (ge, gv), task, owner in zip(group, tasks, owners):
-                kname = getattr(compiled.kernel(ge), "__name__", "")
-                out_metas = metas.visit(task, kname)
-                for pos, ranks in _consumer_ranks(comm, task).items():
-                    name, idx = task.writes[pos]
-                    meta = out_metas[pos] if out_metas is not None else None
-                    if rank == owner:
-                        comm.send_tile(_stored_tile(mats[name], idx), ranks, known=meta is not None, meta=meta)
-                        ex.sent(name, idx)
-                    elif rank in ranks:
-                        mats[name].put_tile(comm.recv_tile(owner, meta), *idx)
-                program.post_op(ge, gv, lp.PS.SUCCESS, None)
-                program.set_node_status(ge, gv, lp.NS.FINISHED)
-            comm.transport.end_group()
+            try:
+                for (ge, gv), task, owner in zip(group, tasks, owners):
+                    kname = getattr(compiled.kernel(ge), "__name__", "")
+                    out_metas = metas.visit(task, kname)
+                    for pos, ranks in _consumer_ranks(comm, task).items():
+                        name, idx = task.writes[pos]
+                        meta = out_metas[pos] if out_metas is not None else None
+                        if rank == owner:
+                            comm.send_tile(_stored_tile(mats[name], idx), ranks, known=meta is not None, meta=meta)
+                            ex.sent(name, idx)
+                        elif rank in ranks:
+                            mats[name].put_tile(comm.recv_tile(owner, meta), *idx)
+                    program.post_op(ge, gv, lp.PS.SUCCESS, None)
+                    program.set_node_status(ge, gv, lp.NS.FINISHED)
+            finally:
+                comm.transport.end_group()
         comm.flush()
         be.synchronize()
         ok = job_runner.check_info_flags(program, be)

@@ -50,12 +50,12 @@ def test_comm_world_of_one_self_exchange():
     # the received tile's event is recorded behind the launch at end_group()
     from numpywren_amd.dist import RcclTransport, TileMeta
     tr = RcclTransport.__new__(RcclTransport)
-    tr.be, tr.lib, tr.handle, tr.stream, tr.rank, tr.world, tr._group = be, lib, h.value, cs, 0, 1, None
+    tr.be, tr.lib, tr.handle, tr.stream, tr.rank, tr.world, tr._group, tr._held = be, lib, h.value, cs, 0, 1, None, []
     tr.begin_group()
     tr.send(src, [0])
     got = tr.recv(0, TileMeta(a.shape, a.dtype))
     tr.end_group()
-    assert tr._group is None and np.array_equal(be.to_host(got), a)
+    assert tr._group is None and tr._held == [] and np.array_equal(be.to_host(got), a)
     # the physical device's PCI bus id (what the ranks compare to decide between RCCL and host staging)
     bus = ctypes.create_string_buffer(64)
     _ffi.check(lib.npw_device_pci_bus_id(be.device, bus, 64), "pci_bus_id")
