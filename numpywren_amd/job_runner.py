@@ -82,7 +82,7 @@ class ReductionFusion(object):
     task writes in a matrix whose parent_fn is constant_zeros (the tree's padding).  The default -- the parity mode --
     materialises every Temp tile like the reference."""
 
-    def __init__(self, compiled):
+    def __init__(self, compiled, acc=None):
         self.compiled = compiled
         readers = collections.defaultdict(list)
         for t in compiled.tasks:
@@ -135,7 +135,9 @@ class ReductionFusion(object):
                     else:
                         stack.append(w)
             self.roots[t.index] = leaves
-        self.acc = {}            # root index -> the accumulating DeviceTile
+        # root index -> the accumulating DeviceTile.  Kept by the caller (the program) across runs: a run that stops on
+        # its time limit is resumed by a new executor, which must find the sums of the products already done.
+        self.acc = acc if acc is not None else {}
 
     def handles(self, task):
         return task.index in self.root_of
@@ -204,7 +206,7 @@ class LambdaPackExecutor(object):
         self.chain_stmts = []
         self.fusion = None
         if cfg.get("fuse_gemm_reduction", False) and not program.block_sparse and is_local is None:
-            fusion = ReductionFusion(self.compiled)
+            fusion = ReductionFusion(self.compiled, program.__dict__.setdefault("_fusion_acc", {}))
             self.fusion = fusion if fusion.roots else None
         if self.chain_cus:
             self.chain_stmts = [i for i, k in getattr(self.compiled, "_kernels", {}).items()

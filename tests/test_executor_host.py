@@ -336,6 +336,31 @@ def test_gemm_fused_reduction_every_tree_shape(nb, oracle_backend):
     np.testing.assert_allclose(outs[1], outs[0], rtol=1e-13, atol=1e-13)
 
 
+def test_fused_gemm_survives_a_timed_out_run(oracle_backend):
+    """A fused run that stops on its time limit keeps its accumulators with the program; the resuming run finishes the sums."""
+    A, B, C = ALG["gemm_32_8/A"], ALG["gemm_32_8/B"], ALG["gemm_32_8/C"]
+    Ab = BigMatrix("gemmr_A", shape=A.shape, shard_sizes=(8, 8), dtype=A.dtype)
+    Bb = BigMatrix("gemmr_B", shape=B.shape, shard_sizes=(8, 8), dtype=B.dtype)
+    shard_matrix(Ab, A)
+    shard_matrix(Bb, B)
+    program, meta = alg_wrappers.gemm(Ab, Bb)
+    program.config["executor"]["fuse_gemm_reduction"] = True
+    program.start()
+    real = job_runner.time.time
+    ticks = iter([0.0] + [0.0] * 30 + [1e9] * 10000)       # the clock jumps after ~30 looks: a handful of products are done
+    job_runner.time.time = lambda: next(ticks)
+    try:
+        res = job_runner.lambdapack_run(program, timeout=10.0)
+    finally:
+        job_runner.time.time = real
+    done = len(res["executed_messages"])
+    assert 0 < done < 64 and program.program_status() == lp.PS.RUNNING and program._fusion_acc
+    job_runner.lambdapack_run(program)
+    program.wait()
+    assert program.program_status() == lp.PS.SUCCESS
+    np.testing.assert_allclose(meta["outputs"][0].numpy(), C, rtol=1e-12, atol=1e-12)
+
+
 def test_fusion_leaves_other_programs_alone(oracle_backend):
     """Nothing fuses in a program without the gemm -> add_matrices pattern; a Temp tile with a second reader would not
     fuse either (the DAG decides, not the program's name)."""
