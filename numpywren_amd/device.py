@@ -872,7 +872,9 @@ class HipBackend(object):
             xt = X.gemm_bt
             if xt is None:
                 X.gemm_uses += 1
-                if X.gemm_uses >= 2:
+                # (kept copies are private allocations the store's spill tier cannot reclaim: none once HBM is half full)
+                roomy = self.allocated_bytes - self.pooled_bytes + X.nbytes < 0.5 * (self.alloc_limit_bytes or self.total_mem)
+                if X.gemm_uses >= 2 and roomy:
                     xt = X.gemm_bt = self.transpose(X, sh)
                 elif dt == _F64 and other_dim >= self.GEMM_TRANSPOSE_MIN:
                     xt = self.transpose(X, sh)      # fp64: 0.1 ms buys 0.25 ms already on the first product; not kept
