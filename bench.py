@@ -380,8 +380,8 @@ def main():
     elif args.workload == "tsqr":
         # configs[3]: (leaves * 4096) x 4096 fp64 TSQR; leaves in contiguous chunks per GPU, log2(world) exchanged R factors.
         # Every N runs the same problem (strong scaling).  What the reference's wrapper returns is [R, V, T]
-        # (alg_wrappers.py:47); V and T of the 511 nodes are ~290 GB, which fits the HBM of 4 or more GPUs and not of 1 or
-        # 2: there the run is R ONLY (executor.drop_unread_outputs: V / T, which no task reads, are dropped as they are
+        # (alg_wrappers.py:47); V and T of the 511 nodes are 160 GiB, which fit the HBM of 4 or more GPUs beside the input, the R
+        # factors and the workspaces, and not that of 1 or 2: there the run is R ONLY (executor.drop_unread_outputs: V / T, which no task reads, are dropped as they are
         # stored) and the line says so.  --keep-vt / --r-only override.
         leaves = args.leaves or 256
         m = leaves * b
