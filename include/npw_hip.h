@@ -211,7 +211,12 @@ int npw_dpotrf_lower_resident_cus(int64_t n);
  * numpywren/kernels.py:86-105,127-130; f2py dgeqrt3 + post-processing).
  * m < n (the reference's slow_qr, kernels.py:67-84: DGEQRF + DLARFT): k = m reflectors
  * from the leading m x m block; V is m x m, T m x m and R the m x n upper trapezoid
- * [R1 | Q^T A2] (ldv, ldt >= m; ldr >= n).                                       */
+ * [R1 | Q^T A2] (ldv, ldt >= m; ldr >= n).
+ * T == NULL (m >= n; here and in the two batched forms): an explicit "R only" request -- the
+ * n x n compact-WY factor is neither returned nor assembled beyond the diagonal blocks the
+ * factorisation itself applies; V and R are complete.  The reference always returns T
+ * (kernels.py:104-105); the executor asks for this form only for tiles nobody reads, under
+ * its `drop_unread_outputs` option.                                                      */
 size_t npw_dgeqrt_workspace_bytes(int64_t m, int64_t n);
 int npw_dgeqrt(int64_t m, int64_t n, const double* A, int64_t lda, double* V, int64_t ldv,
                double* T, int64_t ldt, double* R, int64_t ldr, void* workspace,
@@ -357,6 +362,9 @@ int npw_dgebd2(int64_t n, double* A, int64_t lda, double* d, double* e, void* wo
  *                       (the GEMM program's A / B panel pushes: SUMMA's traffic as one
  *                       all-to-all-v) and the outputs of one batched group of tasks.  Every
  *                       rank opens and closes its groups at the same points of the sequence.
+ *   npw_comm_abort      a rank that fails in the middle of an exchange drops what it has posted
+ *                       (ncclCommAbort) instead of launching part of a group; afterwards only
+ *                       npw_comm_destroy is valid on the handle.
  * (Control values -- timings, failure flags, the collective time limit -- travel over the
  *  host-side control group, not through this library.)                                  */
 #define NPW_COMM_ID_BYTES 128
@@ -364,6 +372,7 @@ typedef void* npw_comm_t;
 int npw_comm_unique_id(void* id_out, size_t id_bytes);
 int npw_comm_init(npw_comm_t* comm, int rank, int world, const void* unique_id);
 int npw_comm_destroy(npw_comm_t comm);
+int npw_comm_abort(npw_comm_t comm);
 int npw_comm_info(npw_comm_t comm, int* rank, int* world, npw_stream_t* transport_stream);
 int npw_comm_group_start(npw_comm_t comm);
 int npw_comm_group_end(npw_comm_t comm);

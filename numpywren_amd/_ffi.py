@@ -105,6 +105,7 @@ PROTOTYPES = {
     "npw_comm_unique_id": (c_int, [_vp, _sz]),
     "npw_comm_init": (c_int, [POINTER(_vp), c_int, c_int, _vp]),
     "npw_comm_destroy": (c_int, [_vp]),
+    "npw_comm_abort": (c_int, [_vp]),
     "npw_comm_info": (c_int, [_vp, POINTER(c_int), POINTER(c_int), POINTER(_vp)]),
     "npw_comm_group_start": (c_int, [_vp]),
     "npw_comm_group_end": (c_int, [_vp]),

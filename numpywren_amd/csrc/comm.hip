@@ -147,6 +147,21 @@ int npw_comm_destroy(npw_comm_t comm) {
     return NPW_OK;
 }
 
+int npw_comm_abort(npw_comm_t comm) {
+    // ncclCommAbort: drops everything the communicator still has posted or in flight (an open group included) and frees
+    // it without waiting for the peers -- what a rank does when it fails in the middle of an exchange, instead of
+    // launching half a group whose transfers no longer match what its peers posted.  The handle stays valid for
+    // npw_comm_destroy; every other call on it fails.
+    NPW_REQUIRE(comm != nullptr, "npw_comm_abort: NULL communicator");
+    Comm* c = as_comm(comm);
+    if (c->comm != nullptr) {
+        ncclComm_t dead = c->comm;
+        c->comm = nullptr;
+        NPW_NCCL_CHECK(g_rccl.CommAbort(dead));
+    }
+    return NPW_OK;
+}
+
 int npw_comm_info(npw_comm_t comm, int* rank, int* world, npw_stream_t* stream) {
     NPW_REQUIRE(comm != nullptr, "npw_comm_info: NULL communicator");
     Comm* c = as_comm(comm);
@@ -171,6 +186,7 @@ int npw_comm_group_end(npw_comm_t comm) {
 int npw_send_tile(npw_comm_t comm, const void* tile, size_t bytes, int dst, npw_stream_t stream) {
     NPW_REQUIRE(comm != nullptr && (tile != nullptr || bytes == 0), "npw_send_tile: NULL argument");
     Comm* c = as_comm(comm);
+    NPW_REQUIRE(c->comm != nullptr, "npw_send_tile: the communicator has been aborted");
     NPW_REQUIRE(dst >= 0 && dst < c->world, "npw_send_tile: bad destination rank %d", dst);
     if (bytes == 0) return NPW_OK;
     NPW_NCCL_CHECK(g_rccl.Send(tile, bytes, ncclUint8, dst, c->comm, stream ? as_stream(stream) : c->stream));
@@ -180,6 +196,7 @@ int npw_send_tile(npw_comm_t comm, const void* tile, size_t bytes, int dst, npw_
 int npw_recv_tile(npw_comm_t comm, void* tile, size_t bytes, int src, npw_stream_t stream) {
     NPW_REQUIRE(comm != nullptr && (tile != nullptr || bytes == 0), "npw_recv_tile: NULL argument");
     Comm* c = as_comm(comm);
+    NPW_REQUIRE(c->comm != nullptr, "npw_recv_tile: the communicator has been aborted");
     NPW_REQUIRE(src >= 0 && src < c->world, "npw_recv_tile: bad source rank %d", src);
     if (bytes == 0) return NPW_OK;
     NPW_NCCL_CHECK(g_rccl.Recv(tile, bytes, ncclUint8, src, c->comm, stream ? as_stream(stream) : c->stream));
@@ -191,6 +208,7 @@ int npw_bcast_tile(npw_comm_t comm, void* tile, size_t bytes, int root, const in
     NPW_REQUIRE(comm != nullptr && (tile != nullptr || bytes == 0), "npw_bcast_tile: NULL argument");
     NPW_REQUIRE(nmembers >= 0 && (members != nullptr || nmembers == 0), "npw_bcast_tile: bad member list");
     Comm* c = as_comm(comm);
+    NPW_REQUIRE(c->comm != nullptr, "npw_bcast_tile: the communicator has been aborted");
     NPW_REQUIRE(root >= 0 && root < c->world, "npw_bcast_tile: bad root %d", root);
     if (bytes == 0) return NPW_OK;
     hipStream_t s = stream ? as_stream(stream) : c->stream;

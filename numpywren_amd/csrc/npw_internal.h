@@ -89,6 +89,8 @@ struct SideStream {
     hipEvent_t fork = nullptr, join = nullptr;
     hipStream_t stream2 = nullptr;            // a second helper stream (QR: the next block's near updates, off the panel chain)
     hipEvent_t fork2 = nullptr, join2 = nullptr;
+    hipStream_t stream3 = nullptr;            // a third one for chip-filling work beside a latency-bound chain (QR: the superblock
+    hipEvent_t fork3 = nullptr, join3 = nullptr;   // reflectors' far updates); $NPW_QR_FAR_RESERVE_CUS keeps it off that many CUs
 };
 int side_stream(hipStream_t main, SideStream** out);
 

@@ -23,7 +23,33 @@ namespace npw {
 namespace {
 
 constexpr int PB = 32;    // panel width (columns one thread keeps in registers)
-constexpr int OB = 128;   // outer block: PB-wide panels are aggregated into one OB-wide block reflector for the far columns
+constexpr int OB = 128;   // outer block: PB-wide panels are aggregated into one OB-wide block reflector for the columns further right
+// Superblock: OB-wide block reflectors are aggregated once more into one SB-wide reflector (V_S, T_S = the diagonal block
+// of T) for everything right of the superblock's look-ahead window, so that the bulk of the trailing update is k = SB
+// products on 128 x 128 tiles instead of k = 128 products (prologue / epilogue-bound, 4 x the passes over the trailing
+// matrix).  $NPW_QR_SB overrides (a multiple of OB; OB itself gives the two-level scheme of rounds 1 - 3).
+inline int64_t superblock_width(bool tri) {
+    // Measured on batches of 32 4096^2 tiles (round 4, gpurun_out/r04a, r04d): dense 113.6 / 105.2 / 109.4 / 119.7 ms at
+    // SB = 128 / 256 / 512 / 1024 (R only: 83.6 / 79.1 / 82.6 / 91.7) -- wider superblocks make the far products more
+    // efficient and the k = OB updates inside the superblock's window more numerous; stacked triangles (a third of the
+    // update work, growing row counts) 87.7 / 90.2 / 93.3 at 128 / 256 / 512.
+    static const int64_t sb[2] = {[] {
+        const char* e = getenv("NPW_QR_SB");
+        int64_t v = e ? atoll(e) : 256;
+        return (v < OB ? (int64_t)OB : v / OB * OB);
+    }(), [] {
+        const char* e = getenv("NPW_QR_SB_TRI") ? getenv("NPW_QR_SB_TRI") : getenv("NPW_QR_SB");
+        int64_t v = e ? atoll(e) : 128;
+        return (v < OB ? (int64_t)OB : v / OB * OB);
+    }()};
+    return sb[tri ? 1 : 0];
+}
+inline int64_t superblock_width_max() {
+    const int64_t a = superblock_width(false), c = superblock_width(true);
+    return a > c ? a : c;
+}
+constexpr int LA = 2 * OB;  // columns right of a superblock that its blocks' own (k = OB) updates keep current: the panel
+                            // chain's two-block window must never reach into columns that still miss earlier reflectors
 __device__ inline double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -420,7 +446,11 @@ struct QrWorkspace {
     double* YnA;     // the same three for the next block's near updates, which run beside the own block's on another stream
     double* YnB;
     double* YnS;
-    int64_t sX, sG, sTmp, sGb, sPart, sRow, sXn, sXnS;
+    double* F1;      // SB x n     temporaries of the superblock reflector's far update (third helper stream)
+    double* F2;      // SB x n
+    double* Gf;      // 4 x SB x n  split-K scratch of that stream
+    double* Ts;      // n x SB     the diagonal superblocks of T when the caller does not want T (T == NULL)
+    int64_t sX, sG, sTmp, sGb, sPart, sRow, sXn, sXnS, sF, sGf, sTs;
 };
 
 inline size_t align2(size_t x) { return (x + 1) & ~(size_t)1; }
@@ -435,6 +465,9 @@ QrWorkspace carve(void* ws, int64_t m, int64_t n, int count) {
     q.sRow = 4 * PB;
     q.sXn = (int64_t)PB * 2 * OB;
     q.sXnS = (int64_t)32 * PB * 2 * OB;
+    q.sF = (int64_t)align2((size_t)superblock_width_max() * n);
+    q.sGf = 4 * q.sF;
+    q.sTs = q.sF;
     double* p = static_cast<double*>(ws);
     auto take = [&](int64_t stride) {
         double* r = p;
@@ -454,12 +487,16 @@ QrWorkspace carve(void* ws, int64_t m, int64_t n, int count) {
     q.YnA = take(q.sXn);
     q.YnB = take(q.sXn);
     q.YnS = take(q.sXnS);
+    q.F1 = take(q.sF);
+    q.F2 = take(q.sF);
+    q.Gf = take(q.sGf);
+    q.Ts = take(q.sTs);
     return q;
 }
 
 size_t square_workspace_doubles(int64_t m, int64_t n) {
     const QrWorkspace q = carve(nullptr, m, n, 0);   // count 0: only the strides are of interest
-    return (size_t)(2 * q.sX + q.sG + q.sTmp + q.sGb + q.sPart + q.sRow + 4 * q.sXn + 2 * q.sXnS);
+    return (size_t)(2 * q.sX + q.sG + q.sTmp + q.sGb + q.sPart + q.sRow + 4 * q.sXn + 2 * q.sXnS + 2 * q.sF + q.sGf + q.sTs);
 }
 
 inline GemmOpts batched(const Batch& b, int64_t sa, int64_t sb, int64_t sc, int64_t sd) {
@@ -566,6 +603,206 @@ __global__ void move_block_rows_kernel(int ob, int pbw, int64_t c_end, double* W
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Panel-wide (pb <= 32) reflector applied to a narrow column block: the two streaming kernels around reduce_tt_kernel.
+// The generic tilings are a poor fit for these shapes (m = 32 rows of V^T W on 64 x 64 tiles with 256-byte row
+// segments, k = 32 updates that are all prologue and epilogue: 3.5 TFLOP/s and 0.5 TB/s in the round-4 trace of a
+// batch of 32, 48 ms of kernel time per batch for the next block's columns alone).  Both kernels read every element of
+// W2 once, straight from global memory into the MFMA operand layout (16 consecutive lanes = 16 consecutive columns =
+// one 128-byte segment), no LDS staging: they are HBM-bound by construction.
+//   near_vtw_kernel   : P[z][slab] = V[slab rows]^T W2[slab rows]   (pb x nc partial products, one per row slab)
+//   (reduce_tt_kernel : X2 = T^T (sum of the partials [+ Wtop]))
+//   near_update_kernel: W2[slab rows] -= V[slab rows] X2
+// blockIdx.x = row slab of `rs` rows, blockIdx.y = chunk of 64 columns, blockIdx.z = matrix of the batch.
+// ------------------------------------------------------------------------------------------------------------------
+typedef double nd4_t __attribute__((ext_vector_type(4)));
+constexpr int NEAR_NT = 4;             // 16-column MFMA tiles per workgroup (one 64-column chunk)
+
+template <bool EDGE>
+__global__ __launch_bounds__(256) void near_vtw_kernel(int rows, int pb, int nc, const double* V, int64_t ldv, int64_t sV,
+                                                        const double* W, int64_t ldw, int64_t sW, double* P, int rs) {
+    __shared__ double red[2][2 * NEAR_NT * 4 * 64];   // two waves' accumulators (32 KB)
+    const int z = blockIdx.z, slab = blockIdx.x, nslab = gridDim.x;
+    const int c0 = blockIdx.y * 16 * NEAR_NT;
+    V += (int64_t)z * sV;
+    W += (int64_t)z * sW;
+    P += ((int64_t)z * nslab + slab) * pb * nc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int rw = rs >> 2;                      // rows per wave (a multiple of 16)
+    const int r_begin = slab * rs + wave * rw;
+    nd4_t acc[2][NEAR_NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NEAR_NT; ++j) acc[i][j] = nd4_t{0.0, 0.0, 0.0, 0.0};
+    const double* vrow = V + (int64_t)(r_begin + lg) * ldv + li;
+    const double* wrow = W + (int64_t)(r_begin + lg) * ldw + c0 + li;
+    const int ntv = (nc - c0) / 16;              // fast form: 16-column tiles of this chunk inside the matrix
+    // four MFMA steps (16 rows) per round: their 24 loads are in flight together
+    for (int s0 = 0; s0 < rw; s0 += 16) {
+        if (!EDGE && r_begin + s0 >= rows) break;   // (wave-uniform) the fast form only needs whole groups of 16 rows
+        double a0[4], a1[4], bb[4][NEAR_NT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double* vr = vrow + (int64_t)(4 * u) * ldv;
+            const double* wr = wrow + (int64_t)(4 * u) * ldw;
+            if constexpr (!EDGE) {
+                a0[u] = vr[0];
+                a1[u] = vr[16];
+#pragma unroll
+                for (int j = 0; j < NEAR_NT; ++j) bb[u][j] = (j < ntv) ? wr[16 * j] : 0.0;   // (uniform) whole 16-column tiles
+            } else {
+                const bool rok = r_begin + s0 + 4 * u + lg < rows;
+                a0[u] = (rok && li < pb) ? vr[0] : 0.0;
+                a1[u] = (rok && 16 + li < pb) ? vr[16] : 0.0;
+#pragma unroll
+                for (int j = 0; j < NEAR_NT; ++j) bb[u][j] = (rok && c0 + 16 * j + li < nc) ? wr[16 * j] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < NEAR_NT; ++j) {
+                acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], bb[u][j], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], bb[u][j], acc[1][j], 0, 0, 0);
+            }
+        vrow += 16 * ldv;
+        wrow += 16 * ldw;
+    }
+    // (w0 + w2) + (w1 + w3): fixed order, deterministic
+    auto put = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NEAR_NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[slot][((i * NEAR_NT + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+    };
+    auto add = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NEAR_NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += red[slot][((i * NEAR_NT + j) * 4 + r) * 64 + lane];
+    };
+    if (wave >= 2) put(wave - 2);
+    __syncthreads();
+    if (wave < 2) add(wave);
+    __syncthreads();
+    if (wave == 1) put(0);
+    __syncthreads();
+    if (wave == 0) {
+        add(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NEAR_NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mm = 16 * i + lg + 4 * r, col = c0 + 16 * j + li;
+                    if (mm < pb && col < nc) P[(int64_t)mm * nc + col] = acc[i][j][r];
+                }
+    }
+}
+
+template <bool EDGE>
+__global__ __launch_bounds__(256) void near_update_kernel(int rows, int pb, int nc, const double* V, int64_t ldv, int64_t sV,
+                                                           const double* X2, int64_t ldx, int64_t sX, double* W, int64_t ldw,
+                                                           int64_t sW, int rs) {
+    const int z = blockIdx.z, slab = blockIdx.x;
+    const int c0 = blockIdx.y * 16 * NEAR_NT;
+    V += (int64_t)z * sV;
+    W += (int64_t)z * sW;
+    X2 += (int64_t)z * sX;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int rw = rs >> 2;                      // rows per wave (a multiple of 16)
+    const int r_begin = slab * rs + wave * rw;
+    // lane group g takes k = 8 g .. 8 g + 7 at the eight MFMA steps (any bijection does as long as both operands agree):
+    // a lane's eight values of V are then 64 contiguous bytes of one row
+    double bf[8][NEAR_NT];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int j = 0; j < NEAR_NT; ++j) {
+            const int k = 8 * lg + s, col = c0 + 16 * j + li;
+            bf[s][j] = (k < pb && col < nc) ? X2[(int64_t)k * ldx + col] : 0.0;
+        }
+    for (int t = 0; t < rw; t += 16) {
+        if (!EDGE && r_begin + t >= rows) break;  // (wave-uniform) whole groups of 16 rows
+        const int ra = r_begin + t + li;          // the row this lane feeds into the A operand
+        double af[8];
+        if constexpr (!EDGE) {
+            const double2* src = reinterpret_cast<const double2*>(V + (int64_t)ra * ldv + 8 * lg);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const double2 v = src[h];
+                af[2 * h] = v.x;
+                af[2 * h + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) af[s] = (ra < rows && 8 * lg + s < pb) ? V[(int64_t)ra * ldv + 8 * lg + s] : 0.0;
+        }
+        nd4_t acc[NEAR_NT];
+        double cv[NEAR_NT][4];
+#pragma unroll
+        for (int j = 0; j < NEAR_NT; ++j) {
+            acc[j] = nd4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = r_begin + t + lg + 4 * r, col = c0 + 16 * j + li;
+                cv[j][r] = (EDGE ? (row < rows && col < nc) : (16 * j < nc - c0)) ? W[(int64_t)row * ldw + col] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int j = 0; j < NEAR_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], bf[s][j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NEAR_NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = r_begin + t + lg + 4 * r, col = c0 + 16 * j + li;
+                if (EDGE ? (row < rows && col < nc) : (16 * j < nc - c0)) W[(int64_t)row * ldw + col] = cv[j][r] - acc[j][r];
+            }
+    }
+}
+
+// rows per workgroup of the two kernels above: 256 when that already gives the chip a few hundred workgroups, else 64;
+// never more slabs than the partial-product scratch holds
+inline int near_slab_rows(const Batch& b, int64_t rows, int64_t pb, int64_t nc, size_t skcap) {
+    const int64_t chunks = ceil_div(nc, 16 * NEAR_NT);
+    int rs = (ceil_div(rows, 256) * chunks * b.count >= 256) ? 256 : 64;
+    while (rs < 4096 && (size_t)(ceil_div(rows, rs) * pb * nc) > skcap) rs *= 2;
+    return rs;
+}
+// the fast forms need whole 16-column tiles, a full panel, whole groups of 16 rows and 16-byte aligned rows of V
+inline bool near_fast(int64_t rows, int64_t pb, int64_t nc, int rs, const double* Vp, int64_t ldv) {
+    (void)rs;
+    return pb == PB && nc % 16 == 0 && rows % 16 == 0 && ldv % 2 == 0 && (reinterpret_cast<uintptr_t>(Vp) & 15) == 0;
+}
+static const bool near_kernels_on = [] {
+    const char* e = getenv("NPW_QR_NEAR_KERNELS");
+    return e == nullptr || atoi(e) != 0;
+}();
+
+// Split-K factor for X1 = V^T W2 (pb x nc, contraction over `rows`): enough workgroups for the chip.  Panel- and
+// block-wide reflectors run on 64 x 64 tiles (one tile row counted, as tuned in rounds 2 - 3), superblock-wide ones on
+// 128 x 128 tiles.
+inline int64_t wanted_splits(const Batch& b, int64_t pb, int64_t nc, int64_t rows) {
+    const int64_t wgs = (pb >= 256 ? ceil_div(pb, 128) * ceil_div(nc, 128) : ceil_div(nc, 64)) * b.count;
+    int64_t want = 512 / (wgs > 0 ? wgs : 1);
+    const int64_t per = pb <= PB ? 64 : 256;   // panel-wide: latency matters, cut finer
+    if (want > rows / per) want = rows / per;
+    if (want > 32) want = 32;
+    return want;
+}
+// gemm() picks its tiling per problem; a batch of mid-size products fills the chip with 128 x 128 tiles much earlier
+inline bool whole_chip_of_big_tiles(const Batch& b, int64_t m, int64_t n) {
+    return m >= 256 && n >= 256 && ceil_div(m, 128) * ceil_div(n, 128) * b.count >= 256;
+}
+
 // W2 (mp x nc, ld ldv) -= V_p (T_p^T (V_p^T W2)), then its top pb rows (final rows of R) move to Rdst and are
 // zeroed in place (V is zero there).  X1, X2: pb x nc scratch per matrix (strides sX1, sX2); skws: split-K scratch of
 // skcap elements per matrix, the matrices' regions back to back.
@@ -575,17 +812,39 @@ int apply_panel(const Batch& b, const double* Wp, int64_t ldv, int64_t mp, int64
     // X1 = V_p^T W2 is pb x nc with a contraction over all mp rows: split k so that the launch has a few hundred
     // workgroups instead of nc/64
     GemmOpts g1 = batched(b, b.sV, b.sV, 0, sX1);
-    int64_t want = 512 / (ceil_div(nc, 64) * b.count > 0 ? ceil_div(nc, 64) * b.count : 1);
-    if (want > mp / (pb <= PB ? 64 : 256)) want = mp / (pb <= PB ? 64 : 256);  // panel-wide: latency matters, cut finer
-    if (want > 32) want = 32;
+    int64_t want = wanted_splits(b, pb, nc, mp);
     if (skws != nullptr && want > 1 && (size_t)want * pb * nc <= skcap) {
         g1.splitk = (int)want;
         g1.splitk_ws = skws;
     }
+    const bool big = pb >= 256 && whole_chip_of_big_tiles(b, pb, nc);   // a superblock reflector: the batch fills the chip with 128 x 128 tiles
+    g1.force_big = big;
     int rc;
+    if (near_kernels_on && pb <= PB && skws != nullptr && (size_t)pb * nc <= skcap) {
+        // panel-wide reflector: the streaming kernels (per-slab partial products, one small kernel that reduces them in a
+        // fixed order and applies T^T, the rank-pb update)
+        const int rs = near_slab_rows(b, mp, pb, nc, skcap);
+        const dim3 grid((unsigned)ceil_div(mp, rs), (unsigned)ceil_div(nc, 16 * NEAR_NT), (unsigned)b.count);
+        const bool fast = near_fast(mp, pb, nc, rs, Wp, ldv);
+        hipLaunchKernelGGL(fast ? near_vtw_kernel<false> : near_vtw_kernel<true>, grid, dim3(256), 0, s, (int)mp, (int)pb, (int)nc, Wp,
+                           ldv, b.sV, (const double*)W2, ldv, b.sV, skws, rs);
+        NPW_LAUNCH_CHECK();
+        hipLaunchKernelGGL(reduce_tt_kernel<PB>, dim3((unsigned)ceil_div(nc, 16), (unsigned)b.count), dim3(PB * 16), 0, s, (int)pb, nc,
+                           (int)grid.x, skws, (const double*)nullptr, (int64_t)0, (int64_t)0, Tjj, ldt, b.sT, X2, sX2);
+        NPW_LAUNCH_CHECK();
+        hipLaunchKernelGGL(fast ? near_update_kernel<false> : near_update_kernel<true>, grid, dim3(256), 0, s, (int)mp, (int)pb, (int)nc,
+                           Wp, ldv, b.sV, (const double*)X2, nc, sX2, W2, ldv, b.sV, rs);
+        NPW_LAUNCH_CHECK();
+        if (Rdst == nullptr) return NPW_OK;
+        const unsigned gy = (unsigned)(pb < 32 ? pb : 32);
+        hipLaunchKernelGGL(move_rows_kernel, dim3((unsigned)ceil_div(nc, 256), gy, (unsigned)b.count), dim3(256), 0, s, (int)pb, nc,
+                           W2, ldv, b.sV, Rdst, ldr, b.sR);
+        NPW_LAUNCH_CHECK();
+        return NPW_OK;
+    }
     if (pb <= PB && skws != nullptr && (size_t)pb * nc <= skcap) {
-        // panel-wide reflector (on the critical path): the partial products stay in the scratch and ONE small kernel
-        // reduces them and applies T^T
+        // (the same through the generic GEMM tilings: $NPW_QR_NEAR_KERNELS=0, A/B runs)  the partial products stay in the
+        // scratch and ONE small kernel reduces them and applies T^T
         int nsplit = 1;
         g1.splitk_ws = skws;
         g1.splitk_keep = &nsplit;
@@ -597,10 +856,14 @@ int apply_panel(const Batch& b, const double* Wp, int64_t ldv, int64_t mp, int64
     } else {
         rc = gemm<double>('T', 'N', pb, nc, mp, 1.0, Wp, ldv, W2, ldv, 0.0, nullptr, 0, X1, nc, g1, s);
         if (rc) return rc;
-        rc = gemm<double>('T', 'N', pb, nc, pb, 1.0, Tjj, ldt, X1, nc, 0.0, nullptr, 0, X2, nc, batched(b, b.sT, sX1, 0, sX2), s);
+        GemmOpts g2 = batched(b, b.sT, sX1, 0, sX2);
+        g2.force_big = big;
+        rc = gemm<double>('T', 'N', pb, nc, pb, 1.0, Tjj, ldt, X1, nc, 0.0, nullptr, 0, X2, nc, g2, s);
         if (rc) return rc;
     }
-    rc = gemm<double>('N', 'N', mp, nc, pb, -1.0, Wp, ldv, X2, nc, 1.0, W2, ldv, W2, ldv, batched(b, b.sV, sX2, b.sV, b.sV), s);
+    GemmOpts g3 = batched(b, b.sV, sX2, b.sV, b.sV);
+    g3.force_big = pb >= 256 && whole_chip_of_big_tiles(b, mp, nc);
+    rc = gemm<double>('N', 'N', mp, nc, pb, -1.0, Wp, ldv, X2, nc, 1.0, W2, ldv, W2, ldv, g3, s);
     if (rc) return rc;
     if (Rdst == nullptr) return NPW_OK;
     const unsigned gy = (unsigned)(pb < 32 ? pb : 32);
@@ -632,15 +895,30 @@ int apply_tri(const Batch& b, const double* Vbot, int64_t ldv, int64_t rows, int
               double* Wtop, double* Wbot, int64_t nc, double* X1, int64_t sX1, double* X2, int64_t sX2, double* skws,
               size_t skcap, double* Rdst, int64_t ldr, hipStream_t s) {
     GemmOpts g1 = batched(b, b.sV, b.sV, b.sV, sX1);
-    int64_t want = 512 / (ceil_div(nc, 64) * b.count > 0 ? ceil_div(nc, 64) * b.count : 1);
-    if (want > rows / (pb <= PB ? 64 : 256)) want = rows / (pb <= PB ? 64 : 256);
-    if (want > 32) want = 32;
+    int64_t want = wanted_splits(b, pb, nc, rows);
     if (skws != nullptr && want > 1 && (size_t)want * pb * nc <= skcap) {
         g1.splitk = (int)want;
         g1.splitk_ws = skws;
     }
+    const bool big = pb >= 256 && whole_chip_of_big_tiles(b, pb, nc);
+    g1.force_big = big;
     int rc;
-    if (pb <= PB && skws != nullptr && (size_t)pb * nc <= skcap) {
+    bool updated = false;   // Wbot -= Vbot X2 already done (the streaming kernels)
+    if (near_kernels_on && pb <= PB && skws != nullptr && (size_t)pb * nc <= skcap) {
+        updated = true;
+        const int rs = near_slab_rows(b, rows, pb, nc, skcap);
+        const dim3 grid((unsigned)ceil_div(rows, rs), (unsigned)ceil_div(nc, 16 * NEAR_NT), (unsigned)b.count);
+        const bool fast = near_fast(rows, pb, nc, rs, Vbot, ldv);
+        hipLaunchKernelGGL(fast ? near_vtw_kernel<false> : near_vtw_kernel<true>, grid, dim3(256), 0, s, (int)rows, (int)pb, (int)nc,
+                           Vbot, ldv, b.sV, (const double*)Wbot, ldv, b.sV, skws, rs);
+        NPW_LAUNCH_CHECK();
+        hipLaunchKernelGGL(reduce_tt_kernel<PB>, dim3((unsigned)ceil_div(nc, 16), (unsigned)b.count), dim3(PB * 16), 0, s, (int)pb, nc,
+                           (int)grid.x, skws, (const double*)Wtop, ldv, b.sV, Tjj, ldt, b.sT, X2, sX2);
+        NPW_LAUNCH_CHECK();
+        hipLaunchKernelGGL(fast ? near_update_kernel<false> : near_update_kernel<true>, grid, dim3(256), 0, s, (int)rows, (int)pb,
+                           (int)nc, Vbot, ldv, b.sV, (const double*)X2, nc, sX2, Wbot, ldv, b.sV, rs);
+        NPW_LAUNCH_CHECK();
+    } else if (pb <= PB && skws != nullptr && (size_t)pb * nc <= skcap) {
         int nsplit = 1;
         g1.splitk_ws = skws;
         g1.splitk_keep = &nsplit;
@@ -652,12 +930,17 @@ int apply_tri(const Batch& b, const double* Vbot, int64_t ldv, int64_t rows, int
     } else {
         rc = gemm<double>('T', 'N', pb, nc, rows, 1.0, Vbot, ldv, Wbot, ldv, 1.0, Wtop, ldv, X1, nc, g1, s);
         if (rc) return rc;
-        rc = gemm<double>('T', 'N', pb, nc, pb, 1.0, Tjj, ldt, X1, nc, 0.0, nullptr, 0, X2, nc, batched(b, b.sT, sX1, 0, sX2), s);
+        GemmOpts g2 = batched(b, b.sT, sX1, 0, sX2);
+        g2.force_big = big;
+        rc = gemm<double>('T', 'N', pb, nc, pb, 1.0, Tjj, ldt, X1, nc, 0.0, nullptr, 0, X2, nc, g2, s);
         if (rc) return rc;
     }
-    rc = gemm<double>('N', 'N', rows, nc, pb, -1.0, Vbot, ldv, X2, nc, 1.0, Wbot, ldv, Wbot, ldv,
-                      batched(b, b.sV, sX2, b.sV, b.sV), s);
-    if (rc) return rc;
+    if (!updated) {
+        GemmOpts g3 = batched(b, b.sV, sX2, b.sV, b.sV);
+        g3.force_big = pb >= 256 && whole_chip_of_big_tiles(b, rows, nc);
+        rc = gemm<double>('N', 'N', rows, nc, pb, -1.0, Vbot, ldv, X2, nc, 1.0, Wbot, ldv, Wbot, ldv, g3, s);
+        if (rc) return rc;
+    }
     const unsigned gy = (unsigned)(pb < 32 ? pb : 32);
     hipLaunchKernelGGL(move_rows_sub_kernel, dim3((unsigned)ceil_div(nc, 256), gy, (unsigned)b.count), dim3(256), 0, s, (int)pb,
                        nc, Wtop, ldv, b.sV, X2, nc, sX2, Rdst, ldr, b.sR);
@@ -673,44 +956,107 @@ int apply_tri(const Batch& b, const double* Vbot, int64_t ldv, int64_t rows, int
 // e_j on top of a vector with j + 1 leading non-zeros in the lower block: a panel at column j0 only touches its pb
 // pivot rows and the first j0 + pb rows of the lower block, and the result is V = [I; V2] with V2 upper triangular --
 // the same V, T, R as the dense algorithm gives, for about a third of the work.
-int geqrt_core(const Batch& b, int64_t m, int64_t n, bool tri, double* V, int64_t ldv, double* T, int64_t ldt, double* R,
+int geqrt_core(const Batch& b_in, int64_t m, int64_t n, bool tri, double* V, int64_t ldv, double* T, int64_t ldt, double* R,
                int64_t ldr, void* workspace, hipStream_t s) {
-    const QrWorkspace q = carve(workspace, m, n, b.count);
+    const QrWorkspace q = carve(workspace, m, n, b_in.count);
     double* const Vlow = V + n * ldv;  // tri: the lower block
+    const int64_t SB = superblock_width(tri);
+
+    // T == NULL: the caller does not want the compact-WY factor (an "R only" request, see npw_hip.h).  The factorisation
+    // itself needs T's diagonal superblocks; they then live in a strip of the workspace: element (r, c) of the superblock
+    // that starts at column sb0 is Ts[r * SB + (c - sb0)], i.e. (Ts - sb0)[r * SB + c].
+    const bool want_t = T != nullptr;
+    Batch b = b_in;
+    const int64_t ldtb = want_t ? ldt : SB;
+    if (!want_t) {
+        b.sT = q.sTs;
+        NPW_HIP_CHECK(hipMemsetAsync(q.Ts, 0, (size_t)q.sTs * b.count * sizeof(double), s));
+    }
+    auto t_base = [&](int64_t sb0) { return want_t ? T : q.Ts - sb0; };
 
     // sequence tags of the panel kernel's hand-off slots: unique per call (process-wide counter seeded from the
     // clock), panel and column, so that stale slots in a recycled workspace can never look current
     static std::atomic<unsigned long long> call_counter{
         (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() & 0x3fffffffULL};
     const unsigned long long call_tag = (call_counter.fetch_add(1) + 1) << 24;
-    // T's off-diagonal blocks: block column by block column during the factorisation, behind the far updates on the helper
-    // stream, or from the Gram matrix of all reflectors afterwards (the round-2 form).  Measured on 4096^2 tiles
-    // (gpurun_out/r03p, r03q): dense x1 20.09 -> 17.84 ms, x8 40.3 -> 37.4, x16 65.4 -> 63.5, x32 117.2 -> 116.8; stacked
-    // triangles x1 19.6 -> 18.8, x4 26.5 -> 25.0, x8 35.6 -> 35.7, x16 52.0 -> 56.6, x32 89.8 -> 100.4 -- their far updates
-    // are a third of the dense ones, a big batch keeps the helper stream busy already and the extra work delays the
-    // updates the panel chain waits for.  NPW_QR_T_PROGRESSIVE=0 / 1 forces either form (A/B runs).
+    // T outside its diagonal superblocks: superblock column by superblock column during the factorisation (DLARFT's
+    // recurrence, behind the far updates on the third helper stream), or from the Gram matrix of all reflectors
+    // afterwards (bottom-up merges), or -- T == NULL -- not at all.  Round-3 measurements of the per-block form of the
+    // progressive variant on 4096^2 tiles: dense x1 20.09 -> 17.84 ms, x8 40.3 -> 37.4, x32 117.2 -> 116.8; stacked
+    // triangles x1 19.6 -> 18.8, x8 35.6 -> 35.7, x32 89.8 -> 100.4.  NPW_QR_T_PROGRESSIVE=0 / 1 forces either form.
     static const int t_mode = [] {
         const char* e = getenv("NPW_QR_T_PROGRESSIVE");
         return e == nullptr ? -1 : (atoi(e) != 0 ? 1 : 0);
     }();
-    const bool progressive_t = t_mode >= 0 ? t_mode == 1 : (!tri || b.count < 8);
+    const bool progressive_t = want_t && (t_mode >= 0 ? t_mode == 1 : (!tri || b.count < 8));
     SideStream* side = nullptr;
+    SideStream serial_side;
     {
         int rc = side_stream(s, &side);
         if (rc) return rc;
+        // $NPW_QR_SERIAL=1 (developer aid): every launch on the caller's stream -- a kernel trace then shows what each
+        // kernel costs when it has the chip to itself
+        static const bool serial = [] {
+            const char* e = getenv("NPW_QR_SERIAL");
+            return e != nullptr && atoi(e) != 0;
+        }();
+        if (serial) {
+            serial_side = *side;
+            serial_side.stream = serial_side.stream2 = serial_side.stream3 = s;
+            side = &serial_side;
+        }
         NPW_HIP_CHECK(hipEventRecord(side->join, s));  // so that the closing wait is valid for a single block
     }
-    // Two levels of blocking.  The panel chain (latency-bound: one small persistent launch per PB columns) runs on the
+    hipStream_t far = side->stream3;
+    bool far_in_flight = false;   // a far update has been issued: the next `mid` update waits for its first part
+
+    // T[r0:c0, c0:c0+w] = -T[r0:c0, r0:c0] * (V[:, r0:c0]^T V[:, c0:c0+w]) * T[c0:c0+w, c0:c0+w]   (DLARFT's recurrence for a
+    // block column; both diagonal blocks are final).  Tq: base of T for these indices (t_base).  V[:, c0:] is zero above
+    // row c0; tri: V = [I; V2] with V2 upper triangular, so the columns left of c0 end at row c0 of the lower block and the
+    // identity parts contribute nothing off the diagonal.
+    auto t_column = [&](double* Tq, int64_t r0, int64_t c0, int64_t w, double* X1, double* X2, int64_t sX, double* skws,
+                        int64_t skcap, hipStream_t st) -> int {
+        const int64_t rows_out = c0 - r0;
+        if (rows_out <= 0 || w <= 0) return NPW_OK;
+        const int64_t kk = tri ? c0 : m - c0;
+        const double* Aop = tri ? Vlow + r0 : V + c0 * ldv + r0;
+        const double* Bop = tri ? Vlow + c0 : V + c0 * ldv + c0;
+        GemmOpts g1 = batched(b, b.sV, b.sV, 0, sX);
+        const int64_t wgs = ceil_div(rows_out, 64) * ceil_div(w, 64) * b.count;
+        int64_t want = 512 / (wgs > 0 ? wgs : 1);
+        if (want > kk / 256) want = kk / 256;
+        if (want > 32) want = 32;
+        if (want > 1 && want * rows_out * w <= skcap) {
+            g1.splitk = (int)want;
+            g1.splitk_ws = skws;
+        }
+        int rc = gemm<double>('T', 'N', rows_out, w, kk, 1.0, Aop, ldv, Bop, ldv, 0.0, nullptr, 0, X1, w, g1, st);
+        if (rc) return rc;
+        GemmOpts g2 = batched(b, sX, b.sT, 0, sX);
+        rc = gemm<double>('N', 'N', rows_out, w, w, 1.0, X1, w, Tq + c0 * ldtb + c0, ldtb, 0.0, nullptr, 0, X2, w, g2, st);
+        if (rc) return rc;
+        GemmOpts g3 = batched(b, b.sT, sX, 0, b.sT);
+        g3.a_upper_tri = true;
+        return gemm<double>('N', 'N', rows_out, w, rows_out, -1.0, Tq + r0 * ldtb + r0, ldtb, X2, w, 0.0, nullptr, 0,
+                            Tq + r0 * ldtb + c0, ldtb, g3, st);
+    };
+
+    // Three levels of blocking.  The panel chain (latency-bound: one small persistent launch per PB columns) runs on the
     // caller's stream and keeps only the rest of its OWN OB-wide block up to date (PB-wide reflectors, three small
     // launches per panel).  The NEXT block's columns get the same per-panel updates on a second helper stream, beside the
     // chain instead of inside it: the next panel does not read them, only the next block's first panel does (one wait
-    // per block).  Everything further right ("far") is updated once per OB columns on the first helper stream with the
-    // block reflector (V_b, T_b): k = OB GEMMs that read and write the big trailing matrix OB/PB times less often than
-    // per-panel updates would.
+    // per block).  The columns right of that, up to LA columns past the end of the block's SB-wide superblock ("mid"),
+    // are updated once per OB columns on the first helper stream with the block reflector (V_b, T_b).  Everything further
+    // right ("far") is updated once per SUPERBLOCK on the third helper stream with (V_S, T_S): k = SB products on
+    // 128 x 128 tiles that read and write the big trailing matrix SB / OB times less often than per-block updates.
     for (int64_t b0 = 0; b0 < n; b0 += OB) {
         const int64_t ob = (n - b0 < OB) ? n - b0 : OB;
         const int64_t own_end = b0 + ob;
         const int64_t near_end = (own_end + OB < n) ? own_end + OB : n;  // end of the next block
+        const int64_t sb0 = (b0 / SB) * SB;
+        const int64_t sb_end = (sb0 + SB < n) ? sb0 + SB : n;
+        const int64_t mid_end = (sb_end + LA < n) ? sb_end + LA : n;    // end of the columns the block reflectors of this superblock update
+        double* const Tq = t_base(sb0);
         // A batch runs the next block's near updates on the second helper stream (measured on 4096^2 tiles: x32 122.0 ->
         // 116.7 ms per batch, x16 67.0 -> 66.0); a single factorisation keeps them in the chain's own launches -- its
         // three near-update kernels are latency-bound whatever their width, and the extra event per panel costs more than
@@ -718,7 +1064,7 @@ int geqrt_core(const Batch& b, int64_t m, int64_t n, bool tri, double* V, int64_
         const bool split_near = b.count >= 8;
         const int64_t nnext = split_near ? near_end - own_end : 0;
         const int64_t chain_end = split_near ? own_end : near_end;   // columns the chain's own near update covers
-        // the next block's columns were last written by the far update of the previous block (its "part 0")
+        // the next block's columns were last written by the mid update of the previous block (its "part 0")
         // (a single factorisation waits on its own stream, after the block's first panel kernel: one panel time of slack)
         if (split_near && b0 > 0 && nnext > 0) NPW_HIP_CHECK(hipStreamWaitEvent(side->stream2, side->join, 0));
         for (int64_t j0 = b0; j0 < own_end; j0 += PB) {
@@ -731,39 +1077,41 @@ int geqrt_core(const Batch& b, int64_t m, int64_t n, bool tri, double* V, int64_
             const int rpt = (b.count * ceil_div(mp, SLAB) > PANEL_MAX_WGS) ? 2 : 1;
             const int G = (int)ceil_div(mp, SLAB * rpt);
             hipLaunchKernelGGL(rpt == 2 ? qr_panel3_kernel<2> : qr_panel3_kernel<1>, dim3(G, b.count), dim3(SLAB), 0, s, (int)mp, (int)pb, Wp, ldv,
-                               T + j0 * ldt + j0, ldt, R + j0 * ldr + j0, ldr, reinterpret_cast<slot_t*>(q.Part),
+                               Tq + j0 * ldtb + j0, ldtb, R + j0 * ldr + j0, ldr, reinterpret_cast<slot_t*>(q.Part),
                                reinterpret_cast<slot_t*>(q.RowBuf), call_tag + (unsigned long long)(j0 / PB) * 64, b.sV, b.sT,
                                b.sR, q.sPart / 2, q.sRow / 2, tri ? (int)pb : (int)mp, tri ? n - j0 - pb : (int64_t)0);
             NPW_LAUNCH_CHECK();
             if (nnext > 0) {
                 NPW_HIP_CHECK(hipEventRecord(side->fork2, s));
                 NPW_HIP_CHECK(hipStreamWaitEvent(side->stream2, side->fork2, 0));
-                int rc = tri ? apply_tri(b, Vlow + j0, ldv, j0 + pb, pb, T + j0 * ldt + j0, ldt, V + j0 * ldv + own_end,
+                int rc = tri ? apply_tri(b, Vlow + j0, ldv, j0 + pb, pb, Tq + j0 * ldtb + j0, ldtb, V + j0 * ldv + own_end,
                                          Vlow + own_end, nnext, q.YnA, q.sXn, q.YnB, q.sXn, q.YnS, (size_t)q.sXnS,
                                          R + j0 * ldr + own_end, ldr, side->stream2)
-                             : apply_panel(b, Wp, ldv, mp, pb, T + j0 * ldt + j0, ldt, V + j0 * ldv + own_end, nnext, q.YnA, q.sXn,
+                             : apply_panel(b, Wp, ldv, mp, pb, Tq + j0 * ldtb + j0, ldtb, V + j0 * ldv + own_end, nnext, q.YnA, q.sXn,
                                            q.YnB, q.sXn, q.YnS, (size_t)q.sXnS, nullptr, ldr, side->stream2);   // R rows: moved per block, below
                 if (rc) return rc;
             }
             const int64_t nc = chain_end - j0 - pb;
             if (nc > 0) {
                 if (!split_near && j0 == b0 && b0 > 0 && near_end > own_end) NPW_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
-                int rc = tri ? apply_tri(b, Vlow + j0, ldv, j0 + pb, pb, T + j0 * ldt + j0, ldt, Wp + pb, Vlow + j0 + pb, nc, q.XnA,
+                int rc = tri ? apply_tri(b, Vlow + j0, ldv, j0 + pb, pb, Tq + j0 * ldtb + j0, ldtb, Wp + pb, Vlow + j0 + pb, nc, q.XnA,
                                          q.sXn, q.XnB, q.sXn, q.XnS, (size_t)q.sXnS, R + j0 * ldr + j0 + pb, ldr, s)
-                             : apply_panel(b, Wp, ldv, mp, pb, T + j0 * ldt + j0, ldt, Wp + pb, nc, q.XnA, q.sXn, q.XnB, q.sXn,
+                             : apply_panel(b, Wp, ldv, mp, pb, Tq + j0 * ldtb + j0, ldtb, Wp + pb, nc, q.XnA, q.sXn, q.XnB, q.sXn,
                                            q.XnS, (size_t)q.sXnS, nullptr, ldr, s);   // R rows: moved per block, below
                 if (rc) return rc;
             }
         }
         if (nnext > 0) {
-            // the next block's first panel (and this block's row move and far update) start from the updated columns
+            // the next block's first panel (and this block's row move and mid update) start from the updated columns
             NPW_HIP_CHECK(hipEventRecord(side->join2, side->stream2));
             NPW_HIP_CHECK(hipStreamWaitEvent(s, side->join2, 0));
         }
-        const int64_t nfar = n - near_end;
+        const int64_t nmid = mid_end - near_end;
         const bool move_near = !tri && near_end - b0 > PB;   // the dense near updates left R rows behind
-        if (ob > PB || nfar > 0 || move_near || (progressive_t && b0 > 0)) {
-            // block reflector on the side stream: T_b from the Gram matrix of the block's columns, then the far update
+        const bool last_in_sb = own_end == sb_end;
+        const bool far_follows = last_in_sb && (n - mid_end > 0 || (progressive_t && sb0 > 0));
+        if (ob > PB || nmid > 0 || move_near || b0 > sb0 || far_follows) {
+            // block reflector on the side stream: T_b from the Gram matrix of the block's columns, then the mid update
             NPW_HIP_CHECK(hipEventRecord(side->fork, s));   // (behind the wait for join2: covers the second helper stream too)
             NPW_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
             if (move_near) {
@@ -781,66 +1129,80 @@ int geqrt_core(const Batch& b, int64_t m, int64_t n, bool tri, double* V, int64_
                 int64_t want = mb / 256;
                 if (want > 32) want = 32;
                 if (want > q.sX / (ob * ob)) want = q.sX / (ob * ob);
-                if (want > 1) {  // ob x ob output with a contraction over all rows: split k (scratch: X1, free until the far update)
+                if (want > 1) {  // ob x ob output with a contraction over all rows: split k (scratch: X1, free until the mid update)
                     sk.splitk = (int)want;
                     sk.splitk_ws = q.X1;
                 }
                 int rc = gemm<double>('T', 'N', ob, ob, mb, 1.0, Vb, ldv, Vb, ldv, 0.0, nullptr, 0, q.Gb, OB, sk, side->stream);
                 if (rc) return rc;
-                rc = merge_t(b, b0, b0 + ob, PB, T, ldt, q.Gb, OB, q.sGb, b0, q.Tmp, q.sTmp, side->stream);
+                rc = merge_t(b, b0, b0 + ob, PB, Tq, ldtb, q.Gb, OB, q.sGb, b0, q.Tmp, q.sTmp, side->stream);
                 if (rc) return rc;
             }
-            // The far update in two parts: first the block after next -- the only far columns the panel chain touches
+            // the mid columns right of the previous superblock's window still miss that superblock's reflectors until the
+            // first part of its far update is through
+            if (nmid > 0 && far_in_flight) {
+                NPW_HIP_CHECK(hipStreamWaitEvent(side->stream, side->join3, 0));
+                far_in_flight = false;
+            }
+            // The mid update in two parts: first the block after next -- the only mid columns the panel chain touches
             // during the NEXT block -- then the join event, then the rest.  The caller's stream then waits for a short
-            // chain of small launches, not for the big trailing GEMMs.
-            for (int part = 0; part < 2 && nfar > 0; ++part) {
-                const int64_t c0 = (part == 0) ? near_end : ((near_end + OB < n) ? near_end + OB : n);
-                const int64_t c1 = (part == 0) ? ((near_end + OB < n) ? near_end + OB : n) : n;
+            // chain of small launches, not for the bigger GEMMs.
+            for (int part = 0; part < 2 && nmid > 0; ++part) {
+                const int64_t c0 = (part == 0) ? near_end : ((near_end + OB < mid_end) ? near_end + OB : mid_end);
+                const int64_t c1 = (part == 0) ? ((near_end + OB < mid_end) ? near_end + OB : mid_end) : mid_end;
                 if (c1 > c0) {
-                    int rc = tri ? apply_tri(b, Vb, ldv, mb, ob, T + b0 * ldt + b0, ldt, V + b0 * ldv + c0, Vlow + c0, c1 - c0, q.X1,
+                    int rc = tri ? apply_tri(b, Vb, ldv, mb, ob, Tq + b0 * ldtb + b0, ldtb, V + b0 * ldv + c0, Vlow + c0, c1 - c0, q.X1,
                                              q.sX, q.X2, q.sX, q.G, (size_t)q.sG, R + b0 * ldr + c0, ldr, side->stream)
-                                 : apply_panel(b, Vb, ldv, mb, ob, T + b0 * ldt + b0, ldt, V + b0 * ldv + c0, c1 - c0, q.X1, q.sX,
+                                 : apply_panel(b, Vb, ldv, mb, ob, Tq + b0 * ldtb + b0, ldtb, V + b0 * ldv + c0, c1 - c0, q.X1, q.sX,
                                                q.X2, q.sX, q.G, (size_t)q.sG, R + b0 * ldr + c0, ldr, side->stream);
                     if (rc) return rc;
                 }
                 if (part == 0) NPW_HIP_CHECK(hipEventRecord(side->join, side->stream));
             }
-            if (nfar <= 0) NPW_HIP_CHECK(hipEventRecord(side->join, side->stream));
-            if (progressive_t && b0 > 0) {
-                // T's block column of this block, above its diagonal block, DLARFT-style:
-                //   T[0:b0, b] = -T[0:b0, 0:b0] * (V[:, 0:b0]^T V_b) * T_b
-                // behind the far update on the helper stream -- nobody waits for it before the factorisation ends, and the
-                // panel chain leaves most of the chip idle; the same flops as the Gram matrix + bottom-up merges that
-                // used to follow the factorisation with the chip to themselves (x32: 30.7 of 116.7 ms).
-                double* Tcol = T + b0;               // rows 0 .. b0, columns b0 .. b0 + ob
-                GemmOpts g1 = batched(b, b.sV, b.sV, 0, q.sX);
-                const int64_t kk = tri ? b0 : mb;    // tri: V2 is upper triangular, columns < b0 end at row b0
-                const double* Aop = tri ? Vlow : V + b0 * ldv;
-                const double* Bop = tri ? Vlow + b0 : Vb;
-                int64_t want = 512 / ((ceil_div(b0, 64) * ceil_div(ob, 64) * b.count) > 0 ? (ceil_div(b0, 64) * ceil_div(ob, 64) * b.count) : 1);
-                if (want > kk / 256) want = kk / 256;
-                if (want > 32) want = 32;
-                if (want > 1 && (size_t)want * b0 * ob <= (size_t)q.sG) {
-                    g1.splitk = (int)want;
-                    g1.splitk_ws = q.G;
+            if (nmid <= 0) NPW_HIP_CHECK(hipEventRecord(side->join, side->stream));
+            // T's block column of this block inside its superblock (rows sb0 .. b0): T_S has to be complete before the
+            // superblock's reflector is applied
+            if (b0 > sb0) {
+                int rc = t_column(Tq, sb0, b0, ob, q.X1, q.X2, q.sX, q.G, q.sG, side->stream);
+                if (rc) return rc;
+            }
+            if (far_follows) {
+                // the superblock's reflector (V_S, T_S) on the third helper stream, first the columns the next superblock's
+                // mid updates will touch, then the rest; then (progressive T) T's rows above this superblock's diagonal block
+                const int64_t sbw = sb_end - sb0;
+                const int64_t ms = tri ? sb0 + sbw : m - sb0;
+                double* Vs = tri ? Vlow + sb0 : V + sb0 * ldv + sb0;
+                NPW_HIP_CHECK(hipEventRecord(side->fork3, side->stream));
+                NPW_HIP_CHECK(hipStreamWaitEvent(far, side->fork3, 0));
+                for (int part = 0; part < 2 && n - mid_end > 0; ++part) {
+                    const int64_t p0_end = (mid_end + SB < n) ? mid_end + SB : n;
+                    const int64_t c0 = (part == 0) ? mid_end : p0_end;
+                    const int64_t c1 = (part == 0) ? p0_end : n;
+                    if (c1 > c0) {
+                        int rc = tri ? apply_tri(b, Vs, ldv, ms, sbw, Tq + sb0 * ldtb + sb0, ldtb, V + sb0 * ldv + c0, Vlow + c0, c1 - c0,
+                                                 q.F1, q.sF, q.F2, q.sF, q.Gf, (size_t)q.sGf, R + sb0 * ldr + c0, ldr, far)
+                                     : apply_panel(b, Vs, ldv, ms, sbw, Tq + sb0 * ldtb + sb0, ldtb, V + sb0 * ldv + c0, c1 - c0, q.F1,
+                                                   q.sF, q.F2, q.sF, q.Gf, (size_t)q.sGf, R + sb0 * ldr + c0, ldr, far);
+                        if (rc) return rc;
+                    }
+                    if (part == 0) {
+                        NPW_HIP_CHECK(hipEventRecord(side->join3, far));
+                        far_in_flight = true;
+                    }
                 }
-                int rc = gemm<double>('T', 'N', b0, ob, kk, 1.0, Aop, ldv, Bop, ldv, 0.0, nullptr, 0, q.X1, ob, g1, side->stream);
-                if (rc) return rc;
-                GemmOpts g2 = batched(b, q.sX, b.sT, 0, q.sX);
-                rc = gemm<double>('N', 'N', b0, ob, ob, 1.0, q.X1, ob, T + b0 * ldt + b0, ldt, 0.0, nullptr, 0, q.X2, ob, g2,
-                                  side->stream);
-                if (rc) return rc;
-                GemmOpts g3 = batched(b, b.sT, q.sX, 0, b.sT);
-                g3.a_upper_tri = true;
-                rc = gemm<double>('N', 'N', b0, ob, b0, -1.0, T, ldt, q.X2, ob, 0.0, nullptr, 0, Tcol, ldt, g3, side->stream);
-                if (rc) return rc;
+                if (progressive_t && sb0 > 0) {
+                    int rc = t_column(T, 0, sb0, sbw, q.F1, q.F2, q.sF, q.Gf, q.sGf, far);
+                    if (rc) return rc;
+                }
             }
         }
     }
-    NPW_HIP_CHECK(hipEventRecord(side->join, side->stream));  // everything the side stream still has in flight
+    NPW_HIP_CHECK(hipEventRecord(side->join, side->stream));  // everything the helper streams still have in flight
     NPW_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
-    if (n > OB && !progressive_t) {
-        // G = V^T V, then the off-diagonal OB-blocks of T bottom-up (the diagonal ones are final)
+    NPW_HIP_CHECK(hipEventRecord(side->join3, far));
+    NPW_HIP_CHECK(hipStreamWaitEvent(s, side->join3, 0));
+    if (want_t && n > SB && !progressive_t) {
+        // G = V^T V, then the off-diagonal SB-blocks of T bottom-up (the diagonal ones are final)
         // (lower triangle only, and V is lower trapezoidal: tile (i0, j0) sums over the rows from max(i0, j0) on --
         //  a sixth of the full product for a square matrix)
         GemmOpts gg = batched(b, b.sV, b.sV, 0, q.sG);
@@ -854,7 +1216,7 @@ int geqrt_core(const Batch& b, int64_t m, int64_t n, bool tri, double* V, int64_
             rc = gemm<double>('T', 'N', n, n, m, 1.0, V, ldv, V, ldv, 0.0, nullptr, 0, q.G, n, gg, s);
         }
         if (rc) return rc;
-        rc = merge_t(b, 0, n, OB, T, ldt, q.G, n, q.sG, 0, q.Tmp, q.sTmp, s);
+        rc = merge_t(b, 0, n, SB, T, ldt, q.G, n, q.sG, 0, q.Tmp, q.sTmp, s);
         if (rc) return rc;
     }
     return NPW_OK;
@@ -880,7 +1242,8 @@ int npw_dgeqrt(int64_t m, int64_t n, const double* A, int64_t lda, double* V, in
     NPW_REQUIRE(m >= 0 && n >= 0, "npw_dgeqrt: negative dimension");
     if (n == 0) return NPW_OK;
     if (m == 0) return NPW_OK;
-    NPW_REQUIRE(A && V && T && R && workspace, "npw_dgeqrt: NULL argument");
+    NPW_REQUIRE(A && V && R && workspace, "npw_dgeqrt: NULL argument");
+    NPW_REQUIRE(T != nullptr || m >= n, "npw_dgeqrt: T may only be omitted for m >= n");
     if (m < n) {
         // More columns than rows (reference kernels.py:94-95 -> slow_qr 67-84: DGEQRF + DLARFT): k = m reflectors, all
         // of them determined by the leading m x m block A1; the other columns only receive Q^T:
@@ -899,13 +1262,13 @@ int npw_dgeqrt(int64_t m, int64_t n, const double* A, int64_t lda, double* V, in
         if (rc) return rc;
         return gemm<double>('N', 'N', m, n2, m, -1.0, V, ldv, W, n2, 1.0, A + m, lda, R + m, ldr, GemmOpts(), s2);
     }
-    NPW_REQUIRE(lda >= n && ldv >= n && ldt >= n && ldr >= n, "npw_dgeqrt: leading dimension too small");
+    NPW_REQUIRE(lda >= n && ldv >= n && (T == nullptr || ldt >= n) && ldr >= n, "npw_dgeqrt: leading dimension too small");
     NPW_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "npw_dgeqrt: workspace not 16B aligned");
     NPW_REQUIRE((const void*)A != (const void*)V, "npw_dgeqrt: V must not alias A");
     hipStream_t s = as_stream(stream);
     // working copy: the factorisation runs in place inside V
     NPW_HIP_CHECK(hipMemcpy2DAsync(V, ldv * 8, A, lda * 8, n * 8, m, hipMemcpyDeviceToDevice, s));
-    NPW_HIP_CHECK(hipMemset2DAsync(T, ldt * 8, 0, n * 8, n, s));
+    if (T) NPW_HIP_CHECK(hipMemset2DAsync(T, ldt * 8, 0, n * 8, n, s));
     NPW_HIP_CHECK(hipMemset2DAsync(R, ldr * 8, 0, n * 8, n, s));
     return geqrt_core(Batch(), m, n, false, V, ldv, T, ldt, R, ldr, workspace, s);
 }
@@ -922,16 +1285,18 @@ int npw_dgeqrt_batched(int count, int64_t m, int64_t n, const double* const* A, 
     if (count == 0 || n == 0 || m == 0) return NPW_OK;
     NPW_REQUIRE(m >= n, "npw_dgeqrt_batched: m (%lld) < n (%lld): use npw_dgeqrt", (long long)m, (long long)n);
     NPW_REQUIRE(count <= 65535, "npw_dgeqrt_batched: more than 65535 matrices");
-    NPW_REQUIRE(A && V && T && R && workspace, "npw_dgeqrt_batched: NULL argument");
-    NPW_REQUIRE(lda >= n && ldv >= n && ldt >= n && ldr >= n, "npw_dgeqrt_batched: leading dimension too small");
-    NPW_REQUIRE(stride_v >= m * ldv && stride_t >= n * ldt && stride_r >= n * ldr, "npw_dgeqrt_batched: stride too small");
+    NPW_REQUIRE(A && V && R && workspace, "npw_dgeqrt_batched: NULL argument");
+    NPW_REQUIRE(lda >= n && ldv >= n && (T == nullptr || ldt >= n) && ldr >= n, "npw_dgeqrt_batched: leading dimension too small");
+    NPW_REQUIRE(stride_v >= m * ldv && (T == nullptr || stride_t >= n * ldt) && stride_r >= n * ldr, "npw_dgeqrt_batched: stride too small");
     NPW_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "npw_dgeqrt_batched: workspace not 16B aligned");
     hipStream_t s = as_stream(stream);
     for (int z = 0; z < count; ++z) {
         NPW_REQUIRE(A[z] != nullptr, "npw_dgeqrt_batched: A[%d] is NULL", z);
         NPW_HIP_CHECK(hipMemcpy2DAsync(V + (int64_t)z * stride_v, ldv * 8, A[z], lda * 8, n * 8, m, hipMemcpyDeviceToDevice, s));
     }
-    if (stride_t == n * ldt && ldt == n) {
+    if (T == nullptr) {
+        // R only: no compact-WY factor
+    } else if (stride_t == n * ldt && ldt == n) {
         NPW_HIP_CHECK(hipMemsetAsync(T, 0, (size_t)count * n * n * 8, s));
     } else {
         for (int z = 0; z < count; ++z) NPW_HIP_CHECK(hipMemset2DAsync(T + (int64_t)z * stride_t, ldt * 8, 0, n * 8, n, s));
@@ -959,9 +1324,9 @@ int npw_dtpqrt_batched(int count, int64_t n, const double* const* A1, const doub
     NPW_REQUIRE(count >= 0 && n >= 0, "npw_dtpqrt_batched: negative argument");
     if (count == 0 || n == 0) return NPW_OK;
     NPW_REQUIRE(count <= 65535, "npw_dtpqrt_batched: more than 65535 matrices");
-    NPW_REQUIRE(A1 && A2 && V && T && R && workspace, "npw_dtpqrt_batched: NULL argument");
-    NPW_REQUIRE(lda >= n && ldv >= n && ldt >= n && ldr >= n, "npw_dtpqrt_batched: leading dimension too small");
-    NPW_REQUIRE(stride_v >= 2 * n * ldv && stride_t >= n * ldt && stride_r >= n * ldr, "npw_dtpqrt_batched: stride too small");
+    NPW_REQUIRE(A1 && A2 && V && R && workspace, "npw_dtpqrt_batched: NULL argument");
+    NPW_REQUIRE(lda >= n && ldv >= n && (T == nullptr || ldt >= n) && ldr >= n, "npw_dtpqrt_batched: leading dimension too small");
+    NPW_REQUIRE(stride_v >= 2 * n * ldv && (T == nullptr || stride_t >= n * ldt) && stride_r >= n * ldr, "npw_dtpqrt_batched: stride too small");
     NPW_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "npw_dtpqrt_batched: workspace not 16B aligned");
     hipStream_t s = as_stream(stream);
     for (int z = 0; z < count; ++z) {
@@ -969,7 +1334,7 @@ int npw_dtpqrt_batched(int count, int64_t n, const double* const* A1, const doub
         double* Vz = V + (int64_t)z * stride_v;
         NPW_HIP_CHECK(hipMemcpy2DAsync(Vz, ldv * 8, A1[z], lda * 8, n * 8, n, hipMemcpyDeviceToDevice, s));
         NPW_HIP_CHECK(hipMemcpy2DAsync(Vz + n * ldv, ldv * 8, A2[z], lda * 8, n * 8, n, hipMemcpyDeviceToDevice, s));
-        NPW_HIP_CHECK(hipMemset2DAsync(T + (int64_t)z * stride_t, ldt * 8, 0, n * 8, n, s));
+        if (T) NPW_HIP_CHECK(hipMemset2DAsync(T + (int64_t)z * stride_t, ldt * 8, 0, n * 8, n, s));
         NPW_HIP_CHECK(hipMemset2DAsync(R + (int64_t)z * stride_r, ldr * 8, 0, n * 8, n, s));
     }
     Batch b;

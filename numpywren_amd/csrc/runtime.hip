@@ -25,10 +25,13 @@ int set_error(int code, const char* fmt, ...) {
 
 using npw::as_stream;
 
+#include <cstdlib>
+#include <mutex>
 #include <unordered_map>
 
 namespace npw {
 int stream_cu_count_query(hipStream_t s);
+void forget_stream(hipStream_t s);
 
 int side_stream(hipStream_t main, SideStream** out) {
     static thread_local std::unordered_map<hipStream_t, SideStream> table;
@@ -40,19 +43,50 @@ int side_stream(hipStream_t main, SideStream** out) {
         NPW_HIP_CHECK(hipStreamCreateWithFlags(&e.stream2, hipStreamNonBlocking));
         NPW_HIP_CHECK(hipEventCreateWithFlags(&e.fork2, hipEventDisableTiming));
         NPW_HIP_CHECK(hipEventCreateWithFlags(&e.join2, hipEventDisableTiming));
+        // the throughput helper: optionally kept off the leading `reserve` bits of the CU mask (the bits are dealt
+        // round-robin over the XCDs, so every XCD keeps reserve / 8 CUs free of its ~100 us GEMM workgroups for the
+        // latency-bound launches of the other streams)
+        static const int reserve = [] {
+            const char* v = getenv("NPW_QR_FAR_RESERVE_CUS");
+            return v ? atoi(v) : 0;
+        }();
+        const int cus = device_cu_count();
+        if (reserve > 0 && reserve < cus && cus <= 512) {
+            uint32_t mask[16] = {0};
+            for (int cu = reserve; cu < cus; ++cu) mask[cu / 32] |= 1u << (cu % 32);
+            NPW_HIP_CHECK(hipExtStreamCreateWithCUMask(&e.stream3, (uint32_t)((cus + 31) / 32), mask));
+        } else {
+            NPW_HIP_CHECK(hipStreamCreateWithFlags(&e.stream3, hipStreamNonBlocking));
+        }
+        NPW_HIP_CHECK(hipEventCreateWithFlags(&e.fork3, hipEventDisableTiming));
+        NPW_HIP_CHECK(hipEventCreateWithFlags(&e.join3, hipEventDisableTiming));
     }
     *out = &e;
     return NPW_OK;
 }
 
+namespace {
+std::mutex g_cu_cache_mutex;
+std::unordered_map<hipStream_t, int> g_cu_cache;   // process-wide, so that npw_stream_destroy can drop an entry
+}  // namespace
+
 int stream_cu_count(hipStream_t s) {
-    // (cached per stream and host thread: the mask of a stream never changes, the query is a driver call)
-    static thread_local std::unordered_map<hipStream_t, int> cache;
-    auto it = cache.find(s);
-    if (it != cache.end()) return it->second;
+    // (cached per stream: the mask of a stream never changes, the query is a driver call; the entry dies with the stream --
+    //  a recycled handle may belong to a stream with another mask)
+    {
+        std::lock_guard<std::mutex> lock(g_cu_cache_mutex);
+        auto it = g_cu_cache.find(s);
+        if (it != g_cu_cache.end()) return it->second;
+    }
     const int result = stream_cu_count_query(s);
-    cache[s] = result;
+    std::lock_guard<std::mutex> lock(g_cu_cache_mutex);
+    g_cu_cache[s] = result;
     return result;
+}
+
+void forget_stream(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_cu_cache_mutex);
+    g_cu_cache.erase(s);
 }
 
 int device_cu_count() {
@@ -239,7 +273,10 @@ int npw_stream_create_masked(npw_stream_t* stream, const uint32_t* cu_mask, int 
 }
 
 int npw_stream_destroy(npw_stream_t stream) {
-    if (stream) NPW_HIP_CHECK(hipStreamDestroy(as_stream(stream)));
+    if (stream) {
+        npw::forget_stream(as_stream(stream));
+        NPW_HIP_CHECK(hipStreamDestroy(as_stream(stream)));
+    }
     return NPW_OK;
 }
 

@@ -1189,26 +1189,29 @@ class HipBackend(object):
         self._produced(sh, out)
         return out
 
-    def geqrt(self, A, stream=None):
+    def geqrt(self, A, stream=None, want_t=True):
         """Householder QR of the m x n tile with k = min(m, n) reflectors: returns (V m x k unit lower trapezoid,
-        T k x k, R k x n upper) -- for m >= n what the reference's fast_qr returns, for m < n its slow_qr."""
+        T k x k, R k x n upper) -- for m >= n what the reference's fast_qr returns, for m < n its slow_qr.
+        want_t=False (m >= n only): T is None and is not assembled (npw_hip.h: the "R only" request)."""
         self._require_2d(A, "qr_factor")
         sh = self._sh(stream)
         A = self.as_f64(A, sh)
         m, n = A.shape
         k = min(m, n)
+        want_t = want_t or m < n
         V = self.empty((m, k), _F64)
-        T = self.empty((k, k), _F64)
+        T = self.empty((k, k), _F64) if want_t else None
         R = self.empty((k, n), _F64)
         ws = self.alloc(max(16, self.lib.npw_dgeqrt_workspace_bytes(m, n)))
         ws.streams.add(sh)
-        self._use(sh, A, V, T, R)
-        _ffi.check(self.lib.npw_dgeqrt(m, n, A.ptr, n, V.ptr, k, T.ptr, k, R.ptr, n, ws.ptr, sh), "geqrt")
-        self._produced(sh, V, T, R)
+        outs = [t for t in (V, T, R) if t is not None]
+        self._use(sh, A, *outs)
+        _ffi.check(self.lib.npw_dgeqrt(m, n, A.ptr, n, V.ptr, k, T.ptr if want_t else None, k, R.ptr, n, ws.ptr, sh), "geqrt")
+        self._produced(sh, *outs)
         R.upper = (k == n)
         return V, T, R
 
-    def geqrt_batched(self, As, stream=None):
+    def geqrt_batched(self, As, stream=None, want_t=True):
         """QR of several tiles of one shape (m >= n) in lock step (npw_dgeqrt_batched): [(V, T, R), ...], each triple
         what `geqrt` returns for that tile.  The outputs of a batch share three allocations."""
         sh = self._sh(stream)
@@ -1217,33 +1220,35 @@ class HipBackend(object):
             self._require_2d(a, "qr_factor")
         m, n = As[0].shape
         if len(As) == 1 or m < n or any(a.shape != (m, n) for a in As):
-            return [self.geqrt(a, stream) for a in As]
+            return [self.geqrt(a, stream, want_t=want_t) for a in As]
         # the panel kernel's workgroups (count x 256-row slabs) wait for each other: keep a batch within what the
         # device holds at once (2 workgroups per CU)
         cap = max(1, (2 * self.compute_units) // ((m + 255) // 256))
         if len(As) > cap:
             out = []
             for i in range(0, len(As), cap):
-                out.extend(self.geqrt_batched(As[i:i + cap], stream))
+                out.extend(self.geqrt_batched(As[i:i + cap], stream, want_t=want_t))
             return out
         count = len(As)
         vb, tb, rb = m * n * 8, n * n * 8, n * n * 8
-        Vbuf, Tbuf, Rbuf = self.alloc(count * vb), self.alloc(count * tb), self.alloc(count * rb)
+        Vbuf, Rbuf = self.alloc(count * vb), self.alloc(count * rb)
+        Tbuf = self.alloc(count * tb) if want_t else None
         ws = self.alloc(max(16, self.lib.npw_dgeqrt_batched_workspace_bytes(count, m, n)))
         self._use(sh, *As)
         for b in (Vbuf, Tbuf, Rbuf, ws):
-            b.streams.add(sh)
+            if b is not None:
+                b.streams.add(sh)
         ptrs = (ctypes.c_void_p * count)(*[a.ptr for a in As])
-        _ffi.check(self.lib.npw_dgeqrt_batched(count, m, n, ptrs, n, Vbuf.ptr, n, m * n, Tbuf.ptr, n, n * n, Rbuf.ptr, n, n * n,
-                                               ws.ptr, sh), "geqrt_batched")
-        out = [(DeviceTile(Vbuf, (m, n), _F64, z * vb), DeviceTile(Tbuf, (n, n), _F64, z * tb),
+        _ffi.check(self.lib.npw_dgeqrt_batched(count, m, n, ptrs, n, Vbuf.ptr, n, m * n, Tbuf.ptr if want_t else None, n, n * n,
+                                               Rbuf.ptr, n, n * n, ws.ptr, sh), "geqrt_batched")
+        out = [(DeviceTile(Vbuf, (m, n), _F64, z * vb), DeviceTile(Tbuf, (n, n), _F64, z * tb) if want_t else None,
                 DeviceTile(Rbuf, (n, n), _F64, z * rb)) for z in range(count)]
-        self._produced(sh, *[t for triple in out for t in triple])
+        self._produced(sh, *[t for triple in out for t in triple if t is not None])
         for _, _, r in out:
             r.upper = True
         return out
 
-    def tpqrt_batched(self, pairs, stream=None):
+    def tpqrt_batched(self, pairs, stream=None, want_t=True):
         """QR of [x0; x1] for pairs of n x n UPPER TRIANGULAR tiles (npw_dtpqrt_batched; what a TSQR tree node does with
         its children's R factors): [(V 2n x n, T, R), ...] as `geqrt(vstack(x0, x1))` returns them, for a third of the
         work.  The caller vouches for the zeros below the diagonals (tiles flagged `upper`, or `tri(x, "U")` copies)."""
@@ -1255,18 +1260,20 @@ class HipBackend(object):
                 raise ValueError(f"tpqrt: expected pairs of {n} x {n} tiles, got {a.shape} over {c.shape}")
         count = len(pairs)
         vb, tb = 2 * n * n * 8, n * n * 8
-        Vbuf, Tbuf, Rbuf = self.alloc(count * vb), self.alloc(count * tb), self.alloc(count * tb)
+        Vbuf, Rbuf = self.alloc(count * vb), self.alloc(count * tb)
+        Tbuf = self.alloc(count * tb) if want_t else None
         ws = self.alloc(max(16, self.lib.npw_dtpqrt_batched_workspace_bytes(count, n)))
         self._use(sh, *[t for p in pairs for t in p])
         for b in (Vbuf, Tbuf, Rbuf, ws):
-            b.streams.add(sh)
+            if b is not None:
+                b.streams.add(sh)
         p1 = (ctypes.c_void_p * count)(*[a.ptr for a, _ in pairs])
         p2 = (ctypes.c_void_p * count)(*[c.ptr for _, c in pairs])
-        _ffi.check(self.lib.npw_dtpqrt_batched(count, n, p1, p2, n, Vbuf.ptr, n, 2 * n * n, Tbuf.ptr, n, n * n, Rbuf.ptr, n, n * n,
-                                               ws.ptr, sh), "tpqrt_batched")
-        out = [(DeviceTile(Vbuf, (2 * n, n), _F64, z * vb), DeviceTile(Tbuf, (n, n), _F64, z * tb),
+        _ffi.check(self.lib.npw_dtpqrt_batched(count, n, p1, p2, n, Vbuf.ptr, n, 2 * n * n, Tbuf.ptr if want_t else None, n, n * n,
+                                               Rbuf.ptr, n, n * n, ws.ptr, sh), "tpqrt_batched")
+        out = [(DeviceTile(Vbuf, (2 * n, n), _F64, z * vb), DeviceTile(Tbuf, (n, n), _F64, z * tb) if want_t else None,
                 DeviceTile(Rbuf, (n, n), _F64, z * tb)) for z in range(count)]
-        self._produced(sh, *[t for triple in out for t in triple])
+        self._produced(sh, *[t for triple in out for t in triple if t is not None])
         for _, _, r in out:
             r.upper = True
         return out

@@ -116,8 +116,18 @@ class RcclTransport(object):
                 # Only now may a sent tile's last reference go: inside the group RCCL has merely noted the transfer, and a
                 # buffer released before the launch is enqueued could be recycled behind an event that does not cover it.
                 self._held = []
-            for tile in pending:
-                self.be._produced(self.stream, tile)
+            if pending:
+                self.be._produced(self.stream, *pending)   # one event for the whole group
+
+    def abort_group(self):
+        """An exception inside an open group (e.g. the owner's check of a tile against the static plan): launching the
+        part of the group that was posted would pair transfers with the wrong ones on the peers, so the communicator is
+        aborted instead (ncclCommAbort) and this transport is dead.  The peers' matching receives never complete; they
+        leave through the collective time limit / the control group's timeout -- the failure is loud on every rank."""
+        self._group = None
+        self._held = []
+        if self.handle:
+            self.lib.npw_comm_abort(self.handle)
 
     def send(self, tile, dsts):
         be, cs = self.be, self.stream
@@ -170,6 +180,9 @@ class HostTransport(object):
         self.groups += 1      # blocking pairwise operations in the common order: a group changes nothing here
 
     def end_group(self):
+        pass
+
+    def abort_group(self):
         pass
 
     def send(self, tile, dsts):
@@ -333,7 +346,9 @@ def init_process_group(backend=None):
                 buf = ctypes.create_string_buffer(64)
                 dev = int(os.environ.get("LOCAL_RANK", "0")) % n.value
                 if _ffi.lib().npw_device_pci_bus_id(dev, buf, 64) == 0:
-                    mine = buf.value.decode()
+                    # (bus ids are only unique within one host: the pair is what has to differ between ranks)
+                    import socket
+                    mine = (socket.gethostname(), buf.value.decode())
         ids = [None] * world
         if world > 1:
             dist.all_gather_object(ids, mine)
@@ -537,8 +552,11 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
                     comm.send_tile(_stored_tile(mats[r[0]], r[1]), consumers, known=meta is not None, meta=meta)
                 elif rank in consumers:
                     mats[r[0]].put_tile(comm.recv_tile(home, meta), *r[1])
-        finally:
-            comm.transport.end_group()          # (also on an error: a group must never stay open)
+        except BaseException:
+            comm.transport.abort_group()        # a partly posted group must not be launched (see RcclTransport.abort_group)
+            raise
+        else:
+            comm.transport.end_group()
         step, timed_out = 0, False
         while program.program_status() == lp.PS.RUNNING and not program.all_terminators_done():
             node = program.dequeue()
@@ -592,7 +610,10 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
                             mats[name].put_tile(comm.recv_tile(owner, meta), *idx)
                     program.post_op(ge, gv, lp.PS.SUCCESS, None)
                     program.set_node_status(ge, gv, lp.NS.FINISHED)
-            finally:
+            except BaseException:
+                comm.transport.abort_group()
+                raise
+            else:
                 comm.transport.end_group()
         comm.flush()
         be.synchronize()

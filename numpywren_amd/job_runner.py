@@ -273,6 +273,17 @@ class LambdaPackExecutor(object):
             if w in self._unread:
                 self.compiled.matrices[w[0]].delete_block(*w[1])
 
+    def _unwanted(self, tasks):
+        """Per task: the output positions whose tiles `_consumed` will drop as soon as they are stored (nobody reads them
+        and the caller asked for `drop_unread_outputs`), or None when nothing is dropped.  A kernel may return None there."""
+        if not (self.reclaim and self.drop_unread):
+            return None
+        if self._readers_left is None:
+            self._init_reclaim()
+        if not self._unread:
+            return None
+        return [{pos for pos, w in enumerate(t.writes) if w in self._unread} for t in tasks]
+
     # ---- the panel chain beside trailing updates ----
     def chain_companions(self, expr_idx, var_values):
         """For a ready task whose kernel needs whole CUs and whose workgroups wait for one another (kernels.chol): the
@@ -397,7 +408,7 @@ class LambdaPackExecutor(object):
         read_bytes = sum(t.nbytes for t in tiles)
         if device_kernel:
             args = [tiles[j] if kind == "tile" else task.consts[j] for kind, j in task.arg_kinds]
-            with kernels.stream_scope(stream, self.program.info_flags_sink(task), self.exact_zero):
+            with kernels.stream_scope(stream, self.program.info_flags_sink(task), self.exact_zero, self._unwanted([task])):
                 results = compute(*args, **task.kwargs)
         else:
             # arbitrary Python callable from the DSL's scope: give it ndarrays, like the reference does
@@ -421,6 +432,8 @@ class LambdaPackExecutor(object):
         write_bytes = 0
         last = None
         for (m, idx), r in zip(task.writes, results):
+            if r is None and (m, idx) in self._unread:
+                continue   # a tile nobody reads, dropped on store anyway: the kernel did not compute it
             if isinstance(r, DeviceTile):
                 if self.program.block_sparse and self.be.read_flag(self.be.zero_flag(r, stream), stream):
                     self.program.incr_sparse_write(r.nbytes)
@@ -467,7 +480,7 @@ class LambdaPackExecutor(object):
             arg_lists.append([tiles[j] if kind == "tile" else task.consts[j] for kind, j in task.arg_kinds])
             kwargs_list.append(task.kwargs)
         others = self._fence_in(compute, stream)
-        with kernels.stream_scope(stream, self.program.info_flags_sink(tasks[0]), self.exact_zero):
+        with kernels.stream_scope(stream, self.program.info_flags_sink(tasks[0]), self.exact_zero, self._unwanted(tasks)):
             results = compute._npw_batch(self.be, stream, arg_lists, kwargs_list)
         self._fence_out(others, stream)
         flops_fn = getattr(compute, "flops", None)
@@ -482,6 +495,8 @@ class LambdaPackExecutor(object):
             if len(res) != len(task.writes):
                 raise Exception("Expected {0} results, got {1}".format(len(task.writes), len(res)))
             for (m, idx), r in zip(task.writes, res):
+                if r is None and (m, idx) in self._unread:
+                    continue   # dropped on store anyway: not computed
                 mats[m].put_tile(r, *idx)
                 write_bytes += r.nbytes
                 last = r

@@ -25,14 +25,26 @@ _tls = threading.local()
 
 
 @contextlib.contextmanager
-def stream_scope(stream, info_sink=None, exact_zero=True):
-    """Run kernels of this thread on `stream`; Cholesky info flags are appended to `info_sink`."""
+def stream_scope(stream, info_sink=None, exact_zero=True, unwanted=None):
+    """Run kernels of this thread on `stream`; Cholesky info flags are appended to `info_sink`.
+    `unwanted`: per task of the call (one entry for a single task, one per task of a batched call) the set of output
+    positions whose tiles will be dropped as soon as they are stored (the executor's `drop_unread_outputs`); a kernel
+    may return None in such a position instead of computing the tile."""
     prev = getattr(_tls, "ctx", None)
+    prev_unwanted = getattr(_tls, "unwanted", None)
     _tls.ctx = (stream, info_sink, exact_zero)
+    _tls.unwanted = unwanted
     try:
         yield
     finally:
         _tls.ctx = prev
+        _tls.unwanted = prev_unwanted
+
+
+def _all_unwanted(position, ntasks):
+    """True when every task of the current call has output `position` marked as dropped on store."""
+    u = getattr(_tls, "unwanted", None)
+    return bool(u) and len(u) == ntasks and all(position in x for x in u)
 
 
 def _ctx():
@@ -277,10 +289,11 @@ def _qr_factor(be, stream, *blocks, **kwargs):
     """QR of vstack(blocks): (V unit-lower-trapezoid m x n, T n x n upper with Q = I - V T V^T,
     R n x n upper) -- reference kernels.py:127-130 -> fast_qr 86-105 (LAPACK dgeqrt3).  A stack with more columns
     than rows (fast_qr hands it to slow_qr, 94-95 -> 67-84) gives V m x m, T m x m and R m x n."""
+    want_t = not _all_unwanted(1, 1)   # T (output 1) is only left out when the executor will drop it unread
     if _stacked_triangles(blocks):
-        return be.tpqrt_batched([tuple(blocks)], stream)[0]
+        return be.tpqrt_batched([tuple(blocks)], stream, want_t=want_t)[0]
     ins = be.vstack(list(blocks), stream)
-    return be.geqrt(ins, stream)
+    return be.geqrt(ins, stream, want_t=want_t)
 
 
 def _stacked_triangles(blocks):
@@ -299,14 +312,15 @@ def _qr_factor_batch(be, stream, arg_lists, kwargs_list):
     the nodes of one tree level (reference algs.py:30-36) are independent and latency-bound one by one.
     arg_lists[i] are the block tiles of task i; returns [(V, T, R), ...] in the same order."""
     out = [None] * len(arg_lists)
+    want_t = not _all_unwanted(1, len(arg_lists))
     tri = [i for i, blocks in enumerate(arg_lists) if _stacked_triangles(blocks)]
     if tri and len({arg_lists[i][0].shape for i in tri}) == 1:
-        for i, res in zip(tri, be.tpqrt_batched([tuple(arg_lists[i]) for i in tri], stream)):
+        for i, res in zip(tri, be.tpqrt_batched([tuple(arg_lists[i]) for i in tri], stream, want_t=want_t)):
             out[i] = res
     rest = [i for i in range(len(arg_lists)) if out[i] is None]
     if rest:
         ins = [be.vstack(list(arg_lists[i]), stream) for i in rest]
-        for i, res in zip(rest, be.geqrt_batched(ins, stream)):
+        for i, res in zip(rest, be.geqrt_batched(ins, stream, want_t=want_t)):
             out[i] = res
     return out
 

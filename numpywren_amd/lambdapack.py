@@ -401,6 +401,17 @@ class LambdaPackProgram(object):
     def start(self, parallel=False):
         with self._lock:
             self._status = PS.RUNNING
+            # a fresh run, whatever an earlier one on this object left behind (a program that is merely to be RESUMED
+            # after a timed-out lambdapack_run is handed to lambdapack_run again, not to start())
+            self._node_status = {}
+            self._edges = {}
+            self._ready = []
+            self._finished_terminators = set()
+            self._success_pending = False
+        # no worker has been up yet (wait() tells "not started" from "worker gone" by this), and partial sums of an
+        # aborted fused-GEMM run (job_runner.ReductionFusion) must not be accumulated into
+        self._was_up = False
+        self._drop_fusion_accumulators()
         seeds = self.program.starters
         tasks = getattr(self.program, "tasks", None)
         if tasks is not None:
@@ -505,10 +516,16 @@ class LambdaPackProgram(object):
             time.sleep(sleep_time)
             status = self.program_status()
 
+    def _drop_fusion_accumulators(self):
+        acc = self.__dict__.get("_fusion_acc")
+        if acc:
+            acc.clear()   # (in place: a live executor's ReductionFusion holds the same dict)
+
     def free(self):
         with self._lock:
             self._ready = []
             self._edges = {}
+        self._drop_fusion_accumulators()
         marks, self.completion_marks = getattr(self, "completion_marks", None), []
         if marks:   # events of a lambdapack_run(wait=False): nobody may be told to wait for them after free()
             from .device import get_backend

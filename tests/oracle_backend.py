@@ -190,24 +190,25 @@ class OracleBackend(object):
     def block(self, tile, r0, r1, c0, c1, stream=None):
         return HostTile(np.ascontiguousarray(tile.array[r0:r1, c0:c1]))
 
-    def geqrt(self, A, stream=None):
+    # want_t=False: T is None, as on the HIP backend (the executor only asks for it for tiles it drops unread)
+    def geqrt(self, A, stream=None, want_t=True):
         self.calls.append(("geqrt", stream))
         v, t, r = oracle.fast_qr(A.array)
         rt = HostTile(r)
         rt.upper = r.shape[0] == r.shape[1]
-        return HostTile(v), HostTile(t), rt
+        return HostTile(v), (HostTile(t) if want_t or A.array.shape[0] < A.array.shape[1] else None), rt
 
-    def geqrt_batched(self, As, stream=None):
+    def geqrt_batched(self, As, stream=None, want_t=True):
         self.calls.append(("geqrt_batched", len(As)))
         out = []
         for a in As:
             v, t, r = oracle.fast_qr(a.array)
             rt = HostTile(r)
             rt.upper = r.shape[0] == r.shape[1]
-            out.append((HostTile(v), HostTile(t), rt))
+            out.append((HostTile(v), HostTile(t) if want_t else None, rt))
         return out
 
-    def tpqrt_batched(self, pairs, stream=None):
+    def tpqrt_batched(self, pairs, stream=None, want_t=True):
         self.calls.append(("tpqrt_batched", len(pairs)))
         out = []
         for a, c in pairs:
@@ -215,7 +216,7 @@ class OracleBackend(object):
             v, t, r = oracle.fast_qr(np.vstack([a.array, c.array]))
             rt = HostTile(r)
             rt.upper = True
-            out.append((HostTile(v), HostTile(t), rt))
+            out.append((HostTile(v), HostTile(t) if want_t else None, rt))
         return out
 
     def tri(self, tile, uplo, unit_diag=False, stream=None):

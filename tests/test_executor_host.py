@@ -361,6 +361,38 @@ def test_fused_gemm_survives_a_timed_out_run(oracle_backend):
     np.testing.assert_allclose(meta["outputs"][0].numpy(), C, rtol=1e-12, atol=1e-12)
 
 
+def test_restart_after_an_aborted_fused_run_starts_from_clean_sums(oracle_backend):
+    """the fused GEMM's accumulators live with the program; a run that is abandoned half-way and RESTARTED
+    (free() + start(), what bench.py does between steps) must not add the new products to the stale partial sums."""
+    A, B, C = ALG["gemm_32_8/A"], ALG["gemm_32_8/B"], ALG["gemm_32_8/C"]
+    Ab = BigMatrix("gemmx_A", shape=A.shape, shard_sizes=(8, 8), dtype=A.dtype)
+    Bb = BigMatrix("gemmx_B", shape=B.shape, shard_sizes=(8, 8), dtype=B.dtype)
+    shard_matrix(Ab, A)
+    shard_matrix(Bb, B)
+    program, meta = alg_wrappers.gemm(Ab, Bb)
+    program.config["executor"]["fuse_gemm_reduction"] = True
+    program.start()
+    real = job_runner.time.time
+    ticks = iter([0.0] + [0.0] * 30 + [1e9] * 10000)
+    job_runner.time.time = lambda: next(ticks)
+    try:
+        job_runner.lambdapack_run(program, timeout=10.0)
+    finally:
+        job_runner.time.time = real
+    assert program.program_status() == lp.PS.RUNNING and program._fusion_acc      # stopped with partial sums in place
+    program.stop()
+    program.free()
+    assert not program._fusion_acc                                                # ... which free() drops
+    for m in meta["outputs"] + meta["intermediates"]:
+        m.free()
+    program.start()
+    assert not program._fusion_acc and not program._was_up
+    job_runner.lambdapack_run(program)
+    program.wait()
+    assert program.program_status() == lp.PS.SUCCESS
+    np.testing.assert_allclose(meta["outputs"][0].numpy(), C, rtol=1e-12, atol=1e-12)
+
+
 def test_fusion_leaves_other_programs_alone(oracle_backend):
     """Nothing fuses in a program without the gemm -> add_matrices pattern; a Temp tile with a second reader would not
     fuse either (the DAG decides, not the program's name)."""

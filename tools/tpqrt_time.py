@@ -10,7 +10,7 @@ for cnt in (1, 2, 4, 8, 16, 32):
     P = [(R[(2 * i) % 8], R[(2 * i + 1) % 8]) for i in range(cnt)]
     for rep in range(2):
         be.synchronize(); t0 = time.time()
-        r = be.tpqrt_batched(P)
+        r = be.tpqrt_batched(P, want_t=os.environ.get("QR_SOAK_NO_T", "0") != "1")
         be.synchronize(); dt = time.time() - t0
         del r
     print("tpqrt x%d: %.2f ms = %.2f ms per node" % (cnt, dt * 1e3, dt * 1e3 / cnt))
