@@ -35,13 +35,36 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense fp64 matrix peak (vendor spec; 74.
 TILE = 4096
 # 65536^2 on ONE GPU: the anchor of the N > 1 strong-scaling lines, and the curve DESIGN.md section 6 predicts from the
 # measured kernel times (never a measured value: no multi-GPU node has been available to the builder)
-NORTH_STAR_1GPU_TFLOPS = 70.27
-NORTH_STAR_1GPU_SOURCE = "gpurun_out/r03a/bench.json north_star (driver BENCH_r02.json: 70.0)"
-PREDICTED_STRONG_SCALING = {"1": 69.8, "2": 137, "4": 239, "8": 432,
-                            "source": "tools/predict_scaling.py: list-scheduling simulation of dist.py with the measured kernel times, "
-                                      "40 - 64 GB/s per xGMI link and direction (N = 8: 417 - 447)"}
-SYRK_TRAFFIC_BYTES = 2.27e9    # PMC passes of a separate run of this command ((2 x FETCH_SIZE + WRITE_SIZE) per tile update of the tagged kernel)
-SYRK_TRAFFIC_SOURCE = "profiles/r03_bench_pmc.json (rocprofv3 --pmc, separate passes; 1.88e9 - 2.27e9 between boxes, floor of the tile map 1.35e9)"
+
+
+def _predicted_scaling(workload):
+    """The predicted 1 / 2 / 4 / 8-GPU figures of `workload` from profiles/predicted_scaling.json -- written by
+    tools/predict_scaling.py from measured single-GPU kernel times; the ONE table DESIGN.md and BASELINE.md quote too.
+    Never a measured value."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "predicted_scaling.json")) as f:
+            table = json.load(f)
+        return {"source": "profiles/predicted_scaling.json (tools/predict_scaling.py: a simulation, not a measurement)",
+                **table["workloads"][workload]}
+    except Exception:
+        return None
+
+
+def _syrk_traffic():
+    """(bytes per tile update, source) of the trailing-update kernel from the newest profiles/r*_bench_pmc.json: separate
+    rocprofv3 --pmc passes of this command, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / tiles per dispatch (gfx950 reports wide
+    coalesced reads at half their size: MI355X_MICROARCH.md).  Not measured in this process."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc.json")))
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                b_ = json.load(f)["bench"]
+            per_tile = (2.0 * b_["FETCH_SIZE"] + b_["WRITE_SIZE"]) * 1024.0 / b_.get("tiles_per_dispatch", 1)
+            return per_tile, "profiles/" + os.path.basename(path)
+        except Exception:
+            continue
+    return None, None
 
 
 def build_input(be, nb, b, key, rank=0, world=1, owner=None):
@@ -177,6 +200,8 @@ class Runner(object):
         self.be, self.comm, self.streams, self.priority_stream = be, comm, streams, priority_stream
         self.r_only = r_only    # TSQR: drop the V / T factors no task reads as they are stored (executor.drop_unread_outputs)
         self.fuse = False       # GEMM program: executor.fuse_gemm_reduction (the accumulate-in-place mode)
+        self.task_timers = False  # N > 1: executor.task_timers in the extra diagnostic step after the timed region
+        self.last_dist = None   # what dist.lambdapack_run_distributed returned for the last step (its "diag" entry)
         self.pending = []   # (program, meta) enqueued on the device, not yet waited for
 
     def settle(self):
@@ -216,7 +241,8 @@ class Runner(object):
                       "| pending:", len(be._pending), file=sys.stderr)
         else:
             from numpywren_amd import dist
-            dist.lambdapack_run_distributed(program, self.comm, pipeline_width=self.streams, timeout=3600)
+            program.config["executor"]["task_timers"] = self.task_timers
+            self.last_dist = dist.lambdapack_run_distributed(program, self.comm, pipeline_width=self.streams, timeout=3600)
             if program.program_status() != lp.PS.SUCCESS:
                 raise SystemExit(f"program failed: {program.exceptions}")
         return meta
@@ -335,8 +361,9 @@ def main():
                                     "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
                                     # HBM-side bytes per launch: PMC passes of ANOTHER run of this command (2 x FETCH_SIZE +
                                     # WRITE_SIZE, profiles/), not measured in this process; only for the 4096^2 tile
-                                    "traffic": SYRK_TRAFFIC_BYTES if b == TILE else None,
-                                    "traffic_unit": "B per tile update; from " + SYRK_TRAFFIC_SOURCE + ", not this run (algorithmic 5.37e8)",
+                                    "traffic": (round(_syrk_traffic()[0]) if _syrk_traffic()[0] else None) if b == TILE else None,
+                                    "traffic_unit": "B per tile update; from %s (rocprofv3 --pmc, separate passes of this command), "
+                                                    "not this run (algorithmic 5.37e8)" % _syrk_traffic()[1],
                                     "launches": len(syrk), "avg_ms": round(avg_ms, 4),
                                     "algorithmic_flop_per_launch": 2 * b ** 3}
                 # launches of the same kernel on the 192-CU partition beside a chol on the other 64 (kernel_ms
@@ -445,14 +472,33 @@ def main():
             line["config"]["fused_mode"] = "executor.fuse_gemm_reduction: fp32 accumulation in place, result converted to fp64 once"
     if comm is not None:
         line["config"]["transport"] = comm.backend
-        line["config"]["bytes_sent_rank0"] = comm.bytes_sent
-        if args.workload == "chol" and world > 1:
-            # the N = 1 point of THIS curve is not the N = 1 line's `value` (configs[1]: 16384^2, what BASELINE.json
+        # The line explains itself (no multi-GPU node was ever available to the builder; the first real run is the driver's):
+        # per rank, what the last TIMED step's common walk cost on the host (`host_walk_ms`), how long the host was blocked on
+        # the device or the control group, how far the device ran behind it (`drain_ms`), and the bytes moved; then ONE extra
+        # step outside the timed region with executor.task_timers: device time by kernel name (`kernel_busy_ms`) and the
+        # transport stream's time inside exchanges (`transfer_wait_ms`: waiting for producers and peers included).
+        timed_diag = (run.last_dist or {}).get("diag")
+        run.task_timers = True
+        build = {"chol": (lambda: alg_wrappers.cholesky(X)), "tsqr": (lambda: alg_wrappers.tsqr(X)),
+                 "gemm32": (lambda: alg_wrappers.gemm(A, B))}[args.workload]
+        e_diag, _ = run.timed(build, 1, 0)
+        run.task_timers = False
+        extra_diag = dict((run.last_dist or {}).get("diag") or {}, step_ms=round(e_diag * 1e3, 3))
+        gathered = [None] * world
+        if world > 1:
+            comm.dist.all_gather_object(gathered, {"timed_step": timed_diag, "diagnostic_step": extra_diag})
+        else:
+            gathered = [{"timed_step": timed_diag, "diagnostic_step": extra_diag}]
+        line["per_rank"] = gathered
+        predicted = _predicted_scaling(args.workload)
+        if predicted is not None:
+            # the N = 1 point of the Cholesky curve is not the N = 1 line's `value` (configs[1]: 16384^2, what BASELINE.json
             # asks that line to report) but its `north_star` object: the same 65536^2 matrix on one GPU
-            line["config"]["strong_scaling_anchor"] = {
-                "what": "the same matrix on 1 GPU = `north_star.tflops` of the N = 1 line (or `bench.py --tiles 16`)",
-                "tflops_last_measured": NORTH_STAR_1GPU_TFLOPS, "source": NORTH_STAR_1GPU_SOURCE,
-                "predicted_tflops_by_gpus": PREDICTED_STRONG_SCALING}
+            line["config"]["predicted"] = predicted
+        if world > 1 and comm.backend != "rccl" and not os.environ.get("NUMPYWREN_AMD_DIST_BACKEND"):
+            raise SystemExit("bench.py --gpus %d: the ranks ended up on the host-staged transport (%s) -- tiles would cross "
+                             "PCIe and host memory instead of xGMI; a number from this run would mean nothing.  Set "
+                             "NUMPYWREN_AMD_DIST_BACKEND=gloo to force it knowingly." % (world, comm.backend))
     if rank == 0:
         print(json.dumps(line))
     if comm is not None:

@@ -68,7 +68,7 @@ __device__ __forceinline__ void unrolled_columns(F& f) {
     }
 }
 
-#ifdef NPW_QR_STAMPS  // developer timing (tools/dbg): where a column's time goes inside workgroup 0, 10 ns units
+#ifdef NPW_QR_STAMPS  // developer timing (tools/qr_stamps.sh): where a column's time goes inside workgroup 0, 10 ns units
 __device__ long long qr_stamps[8];
 #define QR_STAMP(i, t0)                                                           \
     {                                                                             \
@@ -455,7 +455,8 @@ struct QrWorkspace {
 
 inline size_t align2(size_t x) { return (x + 1) & ~(size_t)1; }
 
-QrWorkspace carve(void* ws, int64_t m, int64_t n, int count) {
+// `batch`: the size of the batch the strides are for (small batches run without the superblock level: SB = n)
+QrWorkspace carve(void* ws, int64_t m, int64_t n, int count, int batch) {
     QrWorkspace q;
     q.sX = (int64_t)align2((size_t)OB * n);
     q.sG = (int64_t)align2((size_t)n * n);
@@ -465,9 +466,9 @@ QrWorkspace carve(void* ws, int64_t m, int64_t n, int count) {
     q.sRow = 4 * PB;
     q.sXn = (int64_t)PB * 2 * OB;
     q.sXnS = (int64_t)32 * PB * 2 * OB;
-    q.sF = (int64_t)align2((size_t)superblock_width_max() * n);
+    q.sF = (int64_t)align2((size_t)superblock_width_max() * n);   // (small batches: SB = n, no far update, unused)
     q.sGf = 4 * q.sF;
-    q.sTs = q.sF;
+    q.sTs = batch >= 8 ? q.sF : (int64_t)align2((size_t)ceil_div(n, OB) * OB * n);   // ld = SB (= n rounded up for small batches)
     double* p = static_cast<double*>(ws);
     auto take = [&](int64_t stride) {
         double* r = p;
@@ -494,8 +495,8 @@ QrWorkspace carve(void* ws, int64_t m, int64_t n, int count) {
     return q;
 }
 
-size_t square_workspace_doubles(int64_t m, int64_t n) {
-    const QrWorkspace q = carve(nullptr, m, n, 0);   // count 0: only the strides are of interest
+size_t square_workspace_doubles(int64_t m, int64_t n, int batch) {
+    const QrWorkspace q = carve(nullptr, m, n, 0, batch);   // count 0: only the strides are of interest
     return (size_t)(2 * q.sX + q.sG + q.sTmp + q.sGb + q.sPart + q.sRow + 4 * q.sXn + 2 * q.sXnS + 2 * q.sF + q.sGf + q.sTs);
 }
 
@@ -958,9 +959,11 @@ int apply_tri(const Batch& b, const double* Vbot, int64_t ldv, int64_t rows, int
 // the same V, T, R as the dense algorithm gives, for about a third of the work.
 int geqrt_core(const Batch& b_in, int64_t m, int64_t n, bool tri, double* V, int64_t ldv, double* T, int64_t ldt, double* R,
                int64_t ldr, void* workspace, hipStream_t s) {
-    const QrWorkspace q = carve(workspace, m, n, b_in.count);
+    const QrWorkspace q = carve(workspace, m, n, b_in.count, b_in.count);
     double* const Vlow = V + n * ldv;  // tri: the lower block
-    const int64_t SB = superblock_width(tri);
+    // (small batches are bound by the latency of the panel chain, not by GEMM throughput: the extra launches and waits of
+    //  the third level cost them time -- 4096^2: x1 17.6 ms without it, 19.9 / 27 ms with SB = 256 / 128; x4 26.3 vs 29.0)
+    const int64_t SB = b_in.count >= 8 ? superblock_width(tri) : ((n + OB - 1) / OB) * OB;
 
     // T == NULL: the caller does not want the compact-WY factor (an "R only" request, see npw_hip.h).  The factorisation
     // itself needs T's diagonal superblocks; they then live in a strip of the workspace: element (r, c) of the superblock
@@ -1041,6 +1044,86 @@ int geqrt_core(const Batch& b_in, int64_t m, int64_t n, bool tri, double* V, int
                             Tq + r0 * ldtb + c0, ldtb, g3, st);
     };
 
+    // ---- the far updates: which superblock reflector reaches which columns when -------------------------------------
+    // Reflector S (available once superblock S is factored) has to be applied to every column right of its own window
+    // (mid_end(S)) -- in the order of S for any given column, and to the columns the chain touches next (up to mid_end(S)
+    // + SB) right away.  Default: to ALL columns at once (right-looking), the window first (then the event the next
+    // superblock's updates wait for).  That makes the first superblocks' steps several times longer than the panel chain
+    // beside them and leaves the last ones nothing to do (r04 traces: blocks 0 - 15 of a batch of 32 are bound by the far
+    // stream, 16 - 31 by the chain), so a deadline-ordered schedule with a per-step quota was built as well
+    // ($NPW_QR_FAR_QUOTA = share factor, 1 = equal shares of what is left): step t brings the next window up to date
+    // (every reflector <= t), then reflector t on the columns the older ones have already reached, then as many further
+    // columns -- all reflectors <= t each -- as the step's share allows.  Measured on 32 x 4096^2 (gpurun_out/r04j): R only
+    // 78.0 ms right-looking, 86.7 / 87.0 / 84.9 / 81.4 at quota 0.8 / 1 / 1.3 / 1.7 -- the narrow catch-up strips cost more
+    // than the balance gains (the streams slow each other down whenever they overlap, whatever the order): not the default.
+    // `far_front`: columns < far_front have every reflector < t.
+    static const double far_quota = [] {
+        const char* e = getenv("NPW_QR_FAR_QUOTA");
+        return e ? atof(e) : 0.0;
+    }();
+    const int64_t nsb = ceil_div(n, SB);
+    auto sb_mid_end = [&](int64_t S) {
+        const int64_t e = (S * SB + SB < n ? S * SB + SB : n) + LA;
+        return e < n ? e : n;
+    };
+    auto sb_rows = [&](int64_t S) { return tri ? ((S * SB + SB < n) ? S * SB + SB : n) : m - S * SB; };
+    auto apply_sb = [&](int64_t S, int64_t c0, int64_t c1) -> int {
+        if (c1 <= c0) return NPW_OK;
+        const int64_t s0 = S * SB, sw = ((s0 + SB < n) ? s0 + SB : n) - s0;
+        double* const Ts = t_base(s0) + s0 * ldtb + s0;
+        return tri ? apply_tri(b, Vlow + s0, ldv, s0 + sw, sw, Ts, ldtb, V + s0 * ldv + c0, Vlow + c0, c1 - c0, q.F1, q.sF, q.F2, q.sF,
+                               q.Gf, (size_t)q.sGf, R + s0 * ldr + c0, ldr, far)
+                   : apply_panel(b, V + s0 * ldv + s0, ldv, m - s0, sw, Ts, ldtb, V + s0 * ldv + c0, c1 - c0, q.F1, q.sF, q.F2, q.sF,
+                                 q.Gf, (size_t)q.sGf, R + s0 * ldr + c0, ldr, far);
+    };
+    int64_t far_front = sb_mid_end(0);
+    auto far_step = [&](int64_t t) -> int {
+        const int64_t me = sb_mid_end(t);
+        const int64_t M = (me + SB < n) ? me + SB : n;                       // mandatory: the next window's columns
+        int64_t target = n;
+        if (far_quota > 0.0) {
+            // work in units of rows x columns (the GEMMs' flops / (4 pb)): what is left over all reflectors, shared
+            // equally among the steps that are left
+            double left = 0.0;
+            for (int64_t S = 0; S < nsb; ++S) {
+                const int64_t from = S < t ? far_front : sb_mid_end(S);
+                if (from < n) left += (double)sb_rows(S) * (double)(n - from);
+            }
+            int64_t steps_left = 0;
+            for (int64_t S = t; S < nsb; ++S) steps_left += sb_mid_end(S) < n ? 1 : 0;
+            const double budget = far_quota * left / (double)(steps_left > 0 ? steps_left : 1);
+            double older = 0.0;                                                 // rows of the reflectors < t
+            for (int64_t S = 0; S < t; ++S) older += (double)sb_rows(S);
+            const int64_t base = far_front > M ? far_front : M;                 // columns < base are done after parts 1 - 3
+            double spent = older * (double)(M > far_front ? M - far_front : 0) + (double)sb_rows(t) * (double)(base - me);
+            const double per_col = older + (double)sb_rows(t);
+            int64_t extra = budget > spent ? (int64_t)((budget - spent) / per_col) : 0;
+            extra = (extra / OB) * OB;
+            target = base + extra;
+            if (target > n || n - target < 2 * OB) target = n;                  // no slivers at the end
+        }
+        int rc;
+        for (int64_t S = 0; S < t; ++S) {                                       // 1. older reflectors on the window's new columns
+            rc = apply_sb(S, far_front, M);
+            if (rc) return rc;
+        }
+        rc = apply_sb(t, me, M);                                                // 2. this reflector on the window
+        if (rc) return rc;
+        if (M > me) {
+            NPW_HIP_CHECK(hipEventRecord(side->join3, far));
+            far_in_flight = true;
+        }
+        rc = apply_sb(t, M, far_front);                                         // 3. ... and on the columns the older ones have reached
+        if (rc) return rc;
+        const int64_t base = far_front > M ? far_front : M;
+        for (int64_t S = 0; S <= t && target > base; ++S) {                     // 4. further columns: everything so far
+            rc = apply_sb(S, base, target);
+            if (rc) return rc;
+        }
+        far_front = target > base ? target : base;
+        return NPW_OK;
+    };
+
     // Three levels of blocking.  The panel chain (latency-bound: one small persistent launch per PB columns) runs on the
     // caller's stream and keeps only the rest of its OWN OB-wide block up to date (PB-wide reflectors, three small
     // launches per panel).  The NEXT block's columns get the same per-panel updates on a second helper stream, beside the
@@ -1109,7 +1192,7 @@ int geqrt_core(const Batch& b_in, int64_t m, int64_t n, bool tri, double* V, int
         const int64_t nmid = mid_end - near_end;
         const bool move_near = !tri && near_end - b0 > PB;   // the dense near updates left R rows behind
         const bool last_in_sb = own_end == sb_end;
-        const bool far_follows = last_in_sb && (n - mid_end > 0 || (progressive_t && sb0 > 0));
+        const bool far_follows = last_in_sb && (n - mid_end > 0 || far_front < n || (progressive_t && sb0 > 0));
         if (ob > PB || nmid > 0 || move_near || b0 > sb0 || far_follows) {
             // block reflector on the side stream: T_b from the Gram matrix of the block's columns, then the mid update
             NPW_HIP_CHECK(hipEventRecord(side->fork, s));   // (behind the wait for join2: covers the second helper stream too)
@@ -1167,31 +1250,14 @@ int geqrt_core(const Batch& b_in, int64_t m, int64_t n, bool tri, double* V, int
                 if (rc) return rc;
             }
             if (far_follows) {
-                // the superblock's reflector (V_S, T_S) on the third helper stream, first the columns the next superblock's
-                // mid updates will touch, then the rest; then (progressive T) T's rows above this superblock's diagonal block
-                const int64_t sbw = sb_end - sb0;
-                const int64_t ms = tri ? sb0 + sbw : m - sb0;
-                double* Vs = tri ? Vlow + sb0 : V + sb0 * ldv + sb0;
+                // the superblock reflectors (V_S, T_S) on the third helper stream (see far_step); then (progressive T) T's
+                // rows above this superblock's diagonal block
                 NPW_HIP_CHECK(hipEventRecord(side->fork3, side->stream));
                 NPW_HIP_CHECK(hipStreamWaitEvent(far, side->fork3, 0));
-                for (int part = 0; part < 2 && n - mid_end > 0; ++part) {
-                    const int64_t p0_end = (mid_end + SB < n) ? mid_end + SB : n;
-                    const int64_t c0 = (part == 0) ? mid_end : p0_end;
-                    const int64_t c1 = (part == 0) ? p0_end : n;
-                    if (c1 > c0) {
-                        int rc = tri ? apply_tri(b, Vs, ldv, ms, sbw, Tq + sb0 * ldtb + sb0, ldtb, V + sb0 * ldv + c0, Vlow + c0, c1 - c0,
-                                                 q.F1, q.sF, q.F2, q.sF, q.Gf, (size_t)q.sGf, R + sb0 * ldr + c0, ldr, far)
-                                     : apply_panel(b, Vs, ldv, ms, sbw, Tq + sb0 * ldtb + sb0, ldtb, V + sb0 * ldv + c0, c1 - c0, q.F1,
-                                                   q.sF, q.F2, q.sF, q.Gf, (size_t)q.sGf, R + sb0 * ldr + c0, ldr, far);
-                        if (rc) return rc;
-                    }
-                    if (part == 0) {
-                        NPW_HIP_CHECK(hipEventRecord(side->join3, far));
-                        far_in_flight = true;
-                    }
-                }
+                int rc = far_step(sb0 / SB);
+                if (rc) return rc;
                 if (progressive_t && sb0 > 0) {
-                    int rc = t_column(T, 0, sb0, sbw, q.F1, q.F2, q.sF, q.Gf, q.sGf, far);
+                    rc = t_column(T, 0, sb0, sb_end - sb0, q.F1, q.F2, q.sF, q.Gf, q.sGf, far);
                     if (rc) return rc;
                 }
             }
@@ -1233,7 +1299,7 @@ size_t npw_dgeqrt_workspace_bytes(int64_t m, int64_t n) {
     if (m <= 0 || n <= 0) return 0;
     if (m < n)  // wide: the square factorisation of the leading block + two m x (n - m) GEMM temporaries
         return npw_dgeqrt_workspace_bytes(m, m) + 2 * align2((size_t)m * (n - m)) * sizeof(double);
-    return square_workspace_doubles(m, n) * sizeof(double);
+    return square_workspace_doubles(m, n, 1) * sizeof(double);
 }
 
 int npw_dgeqrt(int64_t m, int64_t n, const double* A, int64_t lda, double* V, int64_t ldv,
@@ -1275,7 +1341,7 @@ int npw_dgeqrt(int64_t m, int64_t n, const double* A, int64_t lda, double* V, in
 
 size_t npw_dgeqrt_batched_workspace_bytes(int count, int64_t m, int64_t n) {
     if (count <= 0 || m <= 0 || n <= 0 || m < n) return 0;
-    return (size_t)count * square_workspace_doubles(m, n) * sizeof(double);
+    return (size_t)count * square_workspace_doubles(m, n, count) * sizeof(double);
 }
 
 int npw_dgeqrt_batched(int count, int64_t m, int64_t n, const double* const* A, int64_t lda, double* V, int64_t ldv,

@@ -538,7 +538,26 @@ class HipBackend(object):
     def trim(self):
         """Return all cached (unused) buffers to the driver."""
         with self._lock:
+            self._stream_ws = {}
             self._trim_locked()
+
+    def stream_workspace(self, sh, nbytes):
+        """Scratch for a library call on stream `sh` that is done with it when the call's launches are: ONE buffer per
+        stream, handed to consecutive calls (they run in order; the factorisations join their helper streams before they
+        return) and grown when a call asks for more.  A fresh allocation per call cannot be recycled before the device
+        has passed it, and the host enqueues a whole program ahead of the device: the 24 batched factorisations of the
+        256-leaf TSQR held 24 x 8 GiB of workspace that way and drove the pool into its ceiling."""
+        nbytes = max(16, int(nbytes))
+        with self._lock:
+            ws = getattr(self, "_stream_ws", None)
+            if ws is None:
+                ws = self._stream_ws = {}
+            cur = ws.get(sh)
+            if cur is None or cur.nbytes < nbytes:
+                cur = self.alloc(nbytes)     # (the old one goes back to the pool behind its streams' events)
+                cur.streams.add(sh)
+                ws[sh] = cur
+        return cur
 
     def alloc(self, nbytes):
         ptr, real = self._alloc_raw(nbytes)
@@ -1202,8 +1221,7 @@ class HipBackend(object):
         V = self.empty((m, k), _F64)
         T = self.empty((k, k), _F64) if want_t else None
         R = self.empty((k, n), _F64)
-        ws = self.alloc(max(16, self.lib.npw_dgeqrt_workspace_bytes(m, n)))
-        ws.streams.add(sh)
+        ws = self.stream_workspace(sh, self.lib.npw_dgeqrt_workspace_bytes(m, n))
         outs = [t for t in (V, T, R) if t is not None]
         self._use(sh, A, *outs)
         _ffi.check(self.lib.npw_dgeqrt(m, n, A.ptr, n, V.ptr, k, T.ptr if want_t else None, k, R.ptr, n, ws.ptr, sh), "geqrt")
@@ -1211,9 +1229,11 @@ class HipBackend(object):
         R.upper = (k == n)
         return V, T, R
 
-    def geqrt_batched(self, As, stream=None, want_t=True):
+    def geqrt_batched(self, As, stream=None, want_t=True, want_v=True):
         """QR of several tiles of one shape (m >= n) in lock step (npw_dgeqrt_batched): [(V, T, R), ...], each triple
-        what `geqrt` returns for that tile.  The outputs of a batch share three allocations."""
+        what `geqrt` returns for that tile.  The outputs of a batch share three allocations.  want_t / want_v = False:
+        that factor is None (T is then not assembled at all, V -- the factorisation's working matrix -- lives in the
+        stream's scratch): the executor's R-only request for tiles it would drop unread."""
         sh = self._sh(stream)
         As = [self.as_f64(a, sh) for a in As]
         for a in As:
@@ -1227,28 +1247,30 @@ class HipBackend(object):
         if len(As) > cap:
             out = []
             for i in range(0, len(As), cap):
-                out.extend(self.geqrt_batched(As[i:i + cap], stream, want_t=want_t))
+                out.extend(self.geqrt_batched(As[i:i + cap], stream, want_t=want_t, want_v=want_v))
             return out
         count = len(As)
         vb, tb, rb = m * n * 8, n * n * 8, n * n * 8
-        Vbuf, Rbuf = self.alloc(count * vb), self.alloc(count * rb)
+        wsb = _round_up(max(16, self.lib.npw_dgeqrt_batched_workspace_bytes(count, m, n)), 256)
+        ws = self.stream_workspace(sh, wsb + (0 if want_v else count * vb))
+        Vbuf, Rbuf = (self.alloc(count * vb) if want_v else None), self.alloc(count * rb)
+        Vptr = Vbuf.ptr if want_v else ws.ptr + wsb
         Tbuf = self.alloc(count * tb) if want_t else None
-        ws = self.alloc(max(16, self.lib.npw_dgeqrt_batched_workspace_bytes(count, m, n)))
         self._use(sh, *As)
-        for b in (Vbuf, Tbuf, Rbuf, ws):
+        for b in (Vbuf, Tbuf, Rbuf):
             if b is not None:
                 b.streams.add(sh)
         ptrs = (ctypes.c_void_p * count)(*[a.ptr for a in As])
-        _ffi.check(self.lib.npw_dgeqrt_batched(count, m, n, ptrs, n, Vbuf.ptr, n, m * n, Tbuf.ptr if want_t else None, n, n * n,
+        _ffi.check(self.lib.npw_dgeqrt_batched(count, m, n, ptrs, n, Vptr, n, m * n, Tbuf.ptr if want_t else None, n, n * n,
                                                Rbuf.ptr, n, n * n, ws.ptr, sh), "geqrt_batched")
-        out = [(DeviceTile(Vbuf, (m, n), _F64, z * vb), DeviceTile(Tbuf, (n, n), _F64, z * tb) if want_t else None,
+        out = [(DeviceTile(Vbuf, (m, n), _F64, z * vb) if want_v else None, DeviceTile(Tbuf, (n, n), _F64, z * tb) if want_t else None,
                 DeviceTile(Rbuf, (n, n), _F64, z * rb)) for z in range(count)]
         self._produced(sh, *[t for triple in out for t in triple if t is not None])
         for _, _, r in out:
             r.upper = True
         return out
 
-    def tpqrt_batched(self, pairs, stream=None, want_t=True):
+    def tpqrt_batched(self, pairs, stream=None, want_t=True, want_v=True):
         """QR of [x0; x1] for pairs of n x n UPPER TRIANGULAR tiles (npw_dtpqrt_batched; what a TSQR tree node does with
         its children's R factors): [(V 2n x n, T, R), ...] as `geqrt(vstack(x0, x1))` returns them, for a third of the
         work.  The caller vouches for the zeros below the diagonals (tiles flagged `upper`, or `tri(x, "U")` copies)."""
@@ -1260,18 +1282,20 @@ class HipBackend(object):
                 raise ValueError(f"tpqrt: expected pairs of {n} x {n} tiles, got {a.shape} over {c.shape}")
         count = len(pairs)
         vb, tb = 2 * n * n * 8, n * n * 8
-        Vbuf, Rbuf = self.alloc(count * vb), self.alloc(count * tb)
+        wsb = _round_up(max(16, self.lib.npw_dtpqrt_batched_workspace_bytes(count, n)), 256)
+        ws = self.stream_workspace(sh, wsb + (0 if want_v else count * vb))
+        Vbuf, Rbuf = (self.alloc(count * vb) if want_v else None), self.alloc(count * tb)
+        Vptr = Vbuf.ptr if want_v else ws.ptr + wsb
         Tbuf = self.alloc(count * tb) if want_t else None
-        ws = self.alloc(max(16, self.lib.npw_dtpqrt_batched_workspace_bytes(count, n)))
         self._use(sh, *[t for p in pairs for t in p])
-        for b in (Vbuf, Tbuf, Rbuf, ws):
+        for b in (Vbuf, Tbuf, Rbuf):
             if b is not None:
                 b.streams.add(sh)
         p1 = (ctypes.c_void_p * count)(*[a.ptr for a, _ in pairs])
         p2 = (ctypes.c_void_p * count)(*[c.ptr for _, c in pairs])
-        _ffi.check(self.lib.npw_dtpqrt_batched(count, n, p1, p2, n, Vbuf.ptr, n, 2 * n * n, Tbuf.ptr if want_t else None, n, n * n,
+        _ffi.check(self.lib.npw_dtpqrt_batched(count, n, p1, p2, n, Vptr, n, 2 * n * n, Tbuf.ptr if want_t else None, n, n * n,
                                                Rbuf.ptr, n, n * n, ws.ptr, sh), "tpqrt_batched")
-        out = [(DeviceTile(Vbuf, (2 * n, n), _F64, z * vb), DeviceTile(Tbuf, (n, n), _F64, z * tb) if want_t else None,
+        out = [(DeviceTile(Vbuf, (2 * n, n), _F64, z * vb) if want_v else None, DeviceTile(Tbuf, (n, n), _F64, z * tb) if want_t else None,
                 DeviceTile(Rbuf, (n, n), _F64, z * tb)) for z in range(count)]
         self._produced(sh, *[t for triple in out for t in triple if t is not None])
         for _, _, r in out:

@@ -98,14 +98,46 @@ class RcclTransport(object):
         self.rank, self.world = rank, world
         self._group = None                # open group: received tiles whose `ready` event is recorded at group end
         self._held = []                   # ... and the tiles being sent: alive until the launch has been enqueued
+        self.diag = False                 # True: every exchange is bracketed with timing events on the transport stream
+        self._spans = []                  # (start event, end event)
+        self._open = None
 
     def begin_group(self):
         """Everything posted until end_group() leaves as ONE RCCL launch (ncclGroupStart / ncclGroupEnd): the sends and
         receives of a group progress side by side on their links instead of one after the other on the transport
         stream.  Every rank opens and closes its groups at the same points of the common task sequence."""
         if self._group is None:
+            self._span_begin()
             _ffi.check(self.lib.npw_comm_group_start(self.handle), "npw_comm_group_start")
             self._group = []
+
+    # ---- diagnostics: how long the transport stream spends inside its exchanges (waiting for the local producers and
+    #      for the peers included -- that IS the time a consumer of these tiles cannot start) ----
+    def _span_begin(self):
+        if self.diag and self._open is None:
+            ev = self.be.new_event(timing=True)
+            self.be.record(ev, self.stream)
+            self._open = ev
+
+    def _span_end(self):
+        if self._open is not None:
+            ev = self.be.new_event(timing=True)
+            self.be.record(ev, self.stream)
+            self._spans.append((self._open, ev))
+            self._open = None
+
+    def exchange_ms(self):
+        """Milliseconds of transport-stream time inside exchanges since the last call (synchronises the stream)."""
+        self._span_end()
+        total = 0.0
+        if self._spans:
+            self.be.stream_sync(self.stream)
+            for a, b in self._spans:
+                total += self.be.elapsed_ms(a, b)
+                self.be.recycle_event(a)
+                self.be.recycle_event(b)
+            self._spans = []
+        return total
 
     def end_group(self):
         if self._group is not None:
@@ -118,6 +150,7 @@ class RcclTransport(object):
                 self._held = []
             if pending:
                 self.be._produced(self.stream, *pending)   # one event for the whole group
+            self._span_end()
 
     def abort_group(self):
         """An exception inside an open group (e.g. the owner's check of a tile against the static plan): launching the
@@ -132,6 +165,9 @@ class RcclTransport(object):
     def send(self, tile, dsts):
         be, cs = self.be, self.stream
         be._use(cs, tile)                 # after the producer; the buffer is not recycled before the send has left
+        single = self._group is None
+        if single:
+            self._span_begin()
         if self._group is not None:
             self._held.append(tile)
             for d in dsts:
@@ -142,16 +178,21 @@ class RcclTransport(object):
             arr = (ctypes.c_int * len(dsts))(*[int(d) for d in dsts])
             _ffi.check(self.lib.npw_bcast_tile(self.handle, tile.ptr, tile.nbytes, self.rank, arr, len(dsts), cs.handle),
                        "npw_bcast_tile")
+        if single:
+            self._span_end()
 
     def recv(self, src, meta):
         be, cs = self.be, self.stream
         tile = be.empty(meta.shape, meta.dtype)
         be._use(cs, tile)
+        if self._group is None:
+            self._span_begin()
         _ffi.check(self.lib.npw_recv_tile(self.handle, tile.ptr, tile.nbytes, int(src), cs.handle), "npw_recv_tile")
         if self._group is not None:
             self._group.append(tile)      # the kernel is launched by end_group(): the event goes behind it
         else:
             be._produced(cs, tile)
+            self._span_end()
         tile.upper = meta.upper
         return tile
 
@@ -175,6 +216,12 @@ class HostTransport(object):
         self.torch, self.control = torch, control
         self.rank, self.world = rank, world
         self.groups = 0
+        self.diag = False
+        self._host_s = 0.0    # host time inside the blocking sends / receives
+
+    def exchange_ms(self):
+        ms, self._host_s = 1e3 * self._host_s, 0.0
+        return ms
 
     def begin_group(self):
         self.groups += 1      # blocking pairwise operations in the common order: a group changes nothing here
@@ -188,12 +235,16 @@ class HostTransport(object):
     def send(self, tile, dsts):
         arr = np.ascontiguousarray(get_backend().to_host(tile))
         flat = self.torch.from_numpy(arr.reshape(-1).view(np.uint8).copy())
+        t0 = time.time()
         for d in dsts:
             self.control.send(flat, int(d))
+        self._host_s += time.time() - t0
 
     def recv(self, src, meta):
         flat = self.torch.empty(max(meta.nbytes, 1), dtype=self.torch.uint8)
+        t0 = time.time()
         self.control.recv(flat, int(src))
+        self._host_s += time.time() - t0
         arr = flat.numpy()[:meta.nbytes].view(meta.dtype).reshape(meta.shape)
         tile = get_backend().to_device(arr)
         tile.upper = meta.upper
@@ -527,6 +578,12 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
     metas = TileMetaPlan(compiled)
     executed = []
     inflight = collections.deque()
+    # diagnostics of this run (returned as "diag"; bench.py prints them per rank on every N > 1 line): host time blocked
+    # on the device or on the control group, per-kernel device time (executor.task_timers), transport-stream time
+    diag_on = bool(((program.config or {}).get("executor", {}) if isinstance(program.config, dict) else {}).get("task_timers", False))
+    comm.transport.diag = diag_on
+    blocked_s = 0.0
+    sent0, recv0 = comm.bytes_sent, comm.bytes_received
     program._defer_success = True
     try:
         # prologue: input tiles read by tasks that live on another rank than the tile itself (one grouped push per tile)
@@ -566,7 +623,10 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
             # over the ranks: a rank that left the walk on its own clock while its peers post the next transfer would
             # leave them waiting inside RCCL for ever.  Every other decision in this loop is a function of the plan.
             if timeout is not None and step % TIMEOUT_CHECK_EVERY == TIMEOUT_CHECK_EVERY - 1:
-                if comm.max_over_ranks(time.time() - t_start) > timeout:
+                t_b = time.time()
+                late = comm.max_over_ranks(t_b - t_start) > timeout
+                blocked_s += time.time() - t_b
+                if late:
                     program._enqueue(node)
                     timed_out = True
                     break
@@ -592,7 +652,9 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
                 if last is not None and last.ready is not None:
                     inflight.append(last)
                     if len(inflight) > max_inflight:
+                        t_b = time.time()
                         be.wait_tile(inflight.popleft())
+                        blocked_s += time.time() - t_b
             # push the outputs to the remote consumers: both sides evaluate the same static plan here; the transfers of
             # one group of tasks (the right-hand sides of a batched solve, the nodes of a tree level) are one launch
             comm.transport.begin_group()
@@ -615,8 +677,10 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
                 raise
             else:
                 comm.transport.end_group()
+        t_walk_end = time.time()
         comm.flush()
         be.synchronize()
+        t_drained = time.time()
         ok = job_runner.check_info_flags(program, be)
         # a failure on any rank fails the program everywhere
         bad = comm.max_over_ranks(0.0 if ok and program.program_status() != lp.PS.EXCEPTION else 1.0)
@@ -629,10 +693,22 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
     finally:
         program._defer_success = False
         program.decr_up(1)
+    diag = {"rank": rank, "transport": comm.backend, "positions": step, "tasks_run_here": len(executed),
+            # the common walk on the host, without the time it spent blocked on the device / the control group
+            "host_walk_ms": round(1e3 * (t_walk_end - t_start - blocked_s), 3),
+            "host_blocked_ms": round(1e3 * blocked_s, 3),
+            # host time between the end of the walk and the device being drained: how far the device ran behind the host
+            "drain_ms": round(1e3 * (t_drained - t_walk_end), 3),
+            "bytes_sent": comm.bytes_sent - sent0, "bytes_received": comm.bytes_received - recv0}
+    if diag_on:
+        times = job_runner.collect_task_times(program)
+        diag["kernel_busy_ms"] = round(sum(v["ms"] for v in times.values()), 3)
+        diag["kernel_ms_by_name"] = {k: round(v["ms"], 3) for k, v in sorted(times.items())}
+        diag["transfer_wait_ms"] = round(comm.transport.exchange_ms(), 3)
     return {"up_time": [t_start, time.time()], "exec_time": [], "executed_messages": executed,
             "operator_refs": [tuple(x) for x in executed], "log": pickle.dumps({}),
             "bytes_sent": comm.bytes_sent, "bytes_received": comm.bytes_received, "transfers": comm.transfers,
-            "headers": comm.headers, "timed_out": timed_out, "steps": step}
+            "headers": comm.headers, "timed_out": timed_out, "steps": step, "diag": diag}
 
 
 def gather_matrix(bigm, comm, root=0):

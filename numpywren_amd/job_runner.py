@@ -190,6 +190,10 @@ class LambdaPackExecutor(object):
         # they are only dropped on store when the caller asks for it by name (an R-only TSQR)
         self.drop_unread = bool(cfg.get("drop_unread_outputs", False))
         self.batch_tasks = max(1, int(cfg.get("batch_tasks", 32)))
+        # diagnostics (off by default: two event records per task cost ~8 us of stream time): every task's kernels are
+        # bracketed with timing events on their stream; collect_task_times() adds them up by kernel name
+        self.task_timers = bool(cfg.get("task_timers", False)) and hasattr(self.be, "new_event")
+        self._task_times = program.__dict__.setdefault("_task_times", [])
         pool = getattr(self.be, "bulk_streams", None) or self.be.streams
         n = max(1, min(int(pipeline_width), len(pool)))
         self.streams = pool[:n]
@@ -213,6 +217,21 @@ class LambdaPackExecutor(object):
                                 if getattr(k, "_npw_chain_resident_cus", None) is not None]
             if not self.chain_stmts:
                 self.chain_cus = 0
+
+    # ---- per-task device timing (executor.task_timers) ----
+    def _tic(self, stream):
+        if not self.task_timers:
+            return None
+        ev = self.be.new_event(timing=True)
+        self.be.record(ev, stream)
+        return ev
+
+    def _toc(self, name, stream, ev0, count=1):
+        if ev0 is None:
+            return
+        ev1 = self.be.new_event(timing=True)
+        self.be.record(ev1, stream)
+        self._task_times.append((name, ev0, ev1, count))
 
     # ---- stream choice ----
     def pick_stream(self, compute):
@@ -408,8 +427,10 @@ class LambdaPackExecutor(object):
         read_bytes = sum(t.nbytes for t in tiles)
         if device_kernel:
             args = [tiles[j] if kind == "tile" else task.consts[j] for kind, j in task.arg_kinds]
+            tic = self._tic(stream)
             with kernels.stream_scope(stream, self.program.info_flags_sink(task), self.exact_zero, self._unwanted([task])):
                 results = compute(*args, **task.kwargs)
+            self._toc(getattr(compute, "__name__", "kernel"), stream, tic)
         else:
             # arbitrary Python callable from the DSL's scope: give it ndarrays, like the reference does
             host = [self.be.to_host(t, stream) for t in tiles]
@@ -480,8 +501,10 @@ class LambdaPackExecutor(object):
             arg_lists.append([tiles[j] if kind == "tile" else task.consts[j] for kind, j in task.arg_kinds])
             kwargs_list.append(task.kwargs)
         others = self._fence_in(compute, stream)
+        tic = self._tic(stream)
         with kernels.stream_scope(stream, self.program.info_flags_sink(tasks[0]), self.exact_zero, self._unwanted(tasks)):
             results = compute._npw_batch(self.be, stream, arg_lists, kwargs_list)
+        self._toc(getattr(compute, "__name__", "kernel"), stream, tic, len(tasks))
         self._fence_out(others, stream)
         flops_fn = getattr(compute, "flops", None)
         last, write_bytes = None, 0
@@ -540,6 +563,26 @@ def _info_sink(program, task):
 
 
 lp.LambdaPackProgram.info_flags_sink = lambda self, task: _info_sink(self, task)
+
+
+def collect_task_times(program):
+    """{kernel name: {"tasks": n, "ms": total device time}} of the tasks run with executor.task_timers since the last call
+    (synchronises the device; with several streams the brackets of concurrent tasks overlap, so the sum can exceed the
+    wall time)."""
+    from .device import get_backend
+    be = get_backend()
+    records = program.__dict__.get("_task_times") or []
+    out = {}
+    if records:
+        be.synchronize()
+        for name, ev0, ev1, count in records:
+            slot = out.setdefault(name, {"tasks": 0, "ms": 0.0})
+            slot["tasks"] += count
+            slot["ms"] += be.elapsed_ms(ev0, ev1)
+            be.recycle_event(ev0)
+            be.recycle_event(ev1)
+        del records[:]
+    return out
 
 
 def check_info_flags(program, be, stream=None):

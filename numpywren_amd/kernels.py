@@ -313,14 +313,15 @@ def _qr_factor_batch(be, stream, arg_lists, kwargs_list):
     arg_lists[i] are the block tiles of task i; returns [(V, T, R), ...] in the same order."""
     out = [None] * len(arg_lists)
     want_t = not _all_unwanted(1, len(arg_lists))
+    want_v = not _all_unwanted(0, len(arg_lists))
     tri = [i for i, blocks in enumerate(arg_lists) if _stacked_triangles(blocks)]
     if tri and len({arg_lists[i][0].shape for i in tri}) == 1:
-        for i, res in zip(tri, be.tpqrt_batched([tuple(arg_lists[i]) for i in tri], stream, want_t=want_t)):
+        for i, res in zip(tri, be.tpqrt_batched([tuple(arg_lists[i]) for i in tri], stream, want_t=want_t, want_v=want_v)):
             out[i] = res
     rest = [i for i in range(len(arg_lists)) if out[i] is None]
     if rest:
         ins = [be.vstack(list(arg_lists[i]), stream) for i in rest]
-        for i, res in zip(rest, be.geqrt_batched(ins, stream, want_t=want_t)):
+        for i, res in zip(rest, be.geqrt_batched(ins, stream, want_t=want_t, want_v=want_v)):
             out[i] = res
     return out
 

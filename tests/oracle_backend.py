@@ -198,17 +198,17 @@ class OracleBackend(object):
         rt.upper = r.shape[0] == r.shape[1]
         return HostTile(v), (HostTile(t) if want_t or A.array.shape[0] < A.array.shape[1] else None), rt
 
-    def geqrt_batched(self, As, stream=None, want_t=True):
+    def geqrt_batched(self, As, stream=None, want_t=True, want_v=True):
         self.calls.append(("geqrt_batched", len(As)))
         out = []
         for a in As:
             v, t, r = oracle.fast_qr(a.array)
             rt = HostTile(r)
             rt.upper = r.shape[0] == r.shape[1]
-            out.append((HostTile(v), HostTile(t) if want_t else None, rt))
+            out.append((HostTile(v) if want_v else None, HostTile(t) if want_t else None, rt))
         return out
 
-    def tpqrt_batched(self, pairs, stream=None, want_t=True):
+    def tpqrt_batched(self, pairs, stream=None, want_t=True, want_v=True):
         self.calls.append(("tpqrt_batched", len(pairs)))
         out = []
         for a, c in pairs:
@@ -216,7 +216,7 @@ class OracleBackend(object):
             v, t, r = oracle.fast_qr(np.vstack([a.array, c.array]))
             rt = HostTile(r)
             rt.upper = True
-            out.append((HostTile(v), HostTile(t) if want_t else None, rt))
+            out.append((HostTile(v) if want_v else None, HostTile(t) if want_t else None, rt))
         return out
 
     def tri(self, tile, uplo, unit_diag=False, stream=None):

@@ -81,6 +81,7 @@ def _worker(rank, world, port, scenario, outdir):
         scatter_owned(X, A, "I")
         program, meta = alg_wrappers.cholesky(X)
         program.config["executor"]["reclaim_intermediates"] = True
+        program.config["executor"]["task_timers"] = True       # the diagnostics of bench.py's N > 1 lines
         program.start()
         res = dist.lambdapack_run_distributed(program, comm, pipeline_width=3)
         assert program.program_status() == lp.PS.SUCCESS, program.exceptions
@@ -92,6 +93,15 @@ def _worker(rank, world, port, scenario, outdir):
             assert sum(counts) == nb * (nb + 1) * (nb + 2) // 6 == 816
             assert min(counts) > 0
         assert res["headers"] == 0 and res["bytes_sent"] > 0
+        # every rank reports what its walk cost: all 816 positions visited, its own share of them executed, bytes both ways
+        d = res["diag"]
+        assert d["rank"] == rank and d["positions"] <= 816 and d["tasks_run_here"] == len(res["executed_messages"])
+        assert d["bytes_sent"] == res["bytes_sent"] and d["bytes_received"] == res["bytes_received"] and d["transport"] == "host"
+        assert d["host_walk_ms"] > 0 and d["host_blocked_ms"] >= 0 and d["drain_ms"] >= 0
+        assert d["transfer_wait_ms"] >= 0 and "kernel_busy_ms" in d
+        with open(os.path.join(outdir, f"diag_{rank}.json"), "w") as f:
+            import json
+            json.dump(d, f)
     elif scenario == "tsqr8":
         # one leaf per rank: every tree edge crosses ranks (the 3 cross-GPU levels of bench.py --workload tsqr --gpus 8)
         Xh = ALG["tsqr_64_8/X"]

@@ -240,6 +240,7 @@ def test_qr_factor_wide_vs_oracle(m, n):
 
 
 @pytest.mark.parametrize("m,n,count", [(64, 64, 2), (200, 67, 5), (256, 128, 3), (512, 300, 4), (1024, 512, 9),
+                                       (1536, 1280, 8), (1400, 1100, 8),   # several superblocks: the far updates of round 4
                                        (2100, 96, 36)])     # 36 x 9 slabs > 256 workgroups: two rows per thread
 def test_qr_batched_equals_one_by_one(m, n, count):
     """npw_dgeqrt_batched: `count` factorisations in lock step give what npw_dgeqrt gives for each (the same kernels
@@ -272,7 +273,37 @@ def test_qr_batched_equals_one_by_one(m, n, count):
     assert mixed[0][0].shape == (m, n) and mixed[1][0].shape == (m + 8, n)
 
 
-@pytest.mark.parametrize("n,count", [(8, 1), (32, 2), (40, 3), (96, 1), (128, 4), (200, 2), (512, 3), (1024, 2),
+@pytest.mark.parametrize("m,n,count,tri", [(300, 200, 1, False), (512, 384, 3, False), (1536, 1280, 8, False), (1400, 1100, 9, False),
+                                           (96, 96, 1, True), (512, 512, 3, True), (1024, 1024, 9, True)])
+def test_qr_r_only_form_gives_the_same_v_and_r(m, n, count, tri):
+    """T == NULL through the C-ABI (npw_hip.h: the "R only" request the executor makes for T tiles it would drop unread):
+    T is not returned, V and R are bit for bit those of the full call -- the factorisation applies the same diagonal
+    blocks of T either way, only their home (a strip of the workspace) and the assembly of the rest differ."""
+    be = kernels.get_backend()
+    rng = np.random.default_rng(m + 3 * n + count)
+    if tri:
+        tiles = [(be.to_device(np.triu(rng.standard_normal((n, n)))), be.to_device(np.triu(rng.standard_normal((n, n)))))
+                 for _ in range(count)]
+        full, lean = be.tpqrt_batched(tiles), be.tpqrt_batched(tiles, want_t=False)
+    else:
+        tiles = [be.to_device(rng.standard_normal((m, n))) for _ in range(count)]
+        full, lean = be.geqrt_batched(tiles), be.geqrt_batched(tiles, want_t=False)
+    for (V, T, R), (V2, T2, R2) in zip(full, lean):
+        assert T is not None and T2 is None and R2.upper
+        assert np.array_equal(be.to_host(V), be.to_host(V2)) and np.array_equal(be.to_host(R), be.to_host(R2))
+    # neither V nor T (a batch whose V tiles are dropped unread as well): the working matrix lives in the stream's scratch
+    bare = be.tpqrt_batched(tiles, want_t=False, want_v=False) if tri else be.geqrt_batched(tiles, want_t=False, want_v=False)
+    for (V, T, R), (V3, T3, R3) in zip(full, bare):
+        assert T3 is None and (V3 is None or count == 1) and np.array_equal(be.to_host(R), be.to_host(R3))
+    # through the kernel seam nothing changes unless the executor says the tile is dropped on store
+    a = rng.standard_normal((96, 64))
+    assert kernels.qr_factor(a)[1] is not None
+    with kernels.stream_scope(None, None, True, unwanted=[{0, 1}]):
+        v, t, r = kernels.qr_factor(a)
+    assert t is None and np.array_equal(r, kernels.qr_factor(a)[2])
+
+
+@pytest.mark.parametrize("n,count", [(8, 1), (32, 2), (40, 3), (96, 1), (128, 4), (200, 2), (512, 3), (1024, 2), (1024, 9),
                                      (512, 60)])     # 60 x 5 slabs > 256 workgroups: the panel kernel's two-rows-per-thread form
 def test_stacked_triangle_qr_equals_dense(n, count):
     """npw_dtpqrt_batched (the node of a TSQR tree: two stacked R factors) against the dense factorisation of the same
