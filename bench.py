@@ -301,8 +301,8 @@ def main():
                          "transit must not block the tasks behind it)")
     ap.add_argument("--priority-stream", action="store_true", help="panel kernels on a high-priority stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--r-only", action="store_true", help="tsqr: drop the V / T factors as they are stored, whatever the GPU count")
-    ap.add_argument("--keep-vt", action="store_true", help="tsqr: keep V / T even if they overflow into host DRAM")
+    ap.add_argument("--r-only", action="store_true", help="tsqr: the timed run drops the V / T factors (no task reads them) instead of producing them")
+    ap.add_argument("--keep-vt", action="store_true", help="tsqr: (the default since round 4; kept for old command lines)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 65536^2 single-GPU run of the N = 1 line")
     args = ap.parse_args()
 
@@ -406,15 +406,15 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(b)
     elif args.workload == "tsqr":
         # configs[3]: (leaves * 4096) x 4096 fp64 TSQR; leaves in contiguous chunks per GPU, log2(world) exchanged R factors.
-        # Every N runs the same problem (strong scaling).  What the reference's wrapper returns is [R, V, T]
-        # (alg_wrappers.py:47); V and T of the 511 nodes are 160 GiB, which fit the HBM of 4 or more GPUs beside the input, the R
-        # factors and the workspaces, and not that of 1 or 2: there the run is R ONLY (executor.drop_unread_outputs: V / T, which no task reads, are dropped as they are
-        # stored) and the line says so.  --keep-vt / --r-only override.
+        # Every N runs the same problem (strong scaling) and returns what the reference's wrapper returns, [R, V, T]
+        # (alg_wrappers.py:47): `value` is that run.  V and T of the 511 nodes are 160 GiB beside 32 GiB of input and 64 GiB
+        # of R factors; since round 4 (one scratch buffer per stream instead of one per call) that fits one 288 GB GPU
+        # without touching the host tier (1.73 s; 7.9 s through it in round 3).  On one GPU the line carries the R-ONLY run
+        # (executor.drop_unread_outputs: V / T, which no task reads, are neither assembled nor stored) beside it, as
+        # `config.r_only`, never instead of it.  --r-only makes it the timed run (and says so in the workload string).
         leaves = args.leaves or 256
         m = leaves * b
-        # (V + T of the 256 leaves and 255 nodes are 160 GiB on top of 32 GiB of input, the R factors in flight and the
-        #  batched factorisation's workspaces: measured on one 288 GB GPU it overflows into the host tier, 7.9 s per run)
-        r_only = args.r_only or (not args.keep_vt and world < 4)
+        r_only = args.r_only
         run.r_only = r_only
         if comm is not None:
             from numpywren_amd import dist
@@ -434,6 +434,13 @@ def main():
                 "config": {"workload": f"{m}x{b} fp64 TSQR, {leaves} leaves, alg_wrappers.tsqr ({2 * leaves - 1} tasks), "
                                        + ("R only (V / T dropped on store)" if r_only else "R, V, T kept (the reference's outputs)"),
                            "r_only": r_only, "tile": b, "streams": args.streams, "parallelism": par}}
+        if comm is None and not r_only:
+            run.r_only = True
+            e2, _ = run.timed(lambda: alg_wrappers.tsqr(X), args.steps, 1)
+            run.r_only = False
+            line["config"]["r_only_run"] = {"what": "the same program with executor.drop_unread_outputs: only the R factors are produced",
+                                            "ms_per_step": round(e2 / args.steps * 1e3, 3),
+                                            "tflops": round(args.steps * flops / e2 / 1e12, 3)}
     else:
         # configs[4]: 32768^2 fp32 GEMM program (fp32 MFMA products, the reference's fp64 add_matrices tree), strong scaling
         nb = args.tiles or 8

@@ -783,6 +783,16 @@ inline bool near_fast(int64_t rows, int64_t pb, int64_t nc, int rs, const double
     (void)rs;
     return pb == PB && nc % 16 == 0 && rows % 16 == 0 && ldv % 2 == 0 && (reinterpret_cast<uintptr_t>(Vp) & 15) == 0;
 }
+static const bool far_nt_form = [] {
+    const char* e = getenv("NPW_QR_FAR_NT");
+    return e == nullptr || atoi(e) != 0;
+}();
+// (128 x 128 tiles for T's block columns: measured slower -- x16 61.3 vs 58.3 ms, x32 105.2 vs 103.6, gpurun_out/r04p: these
+//  products run beside the far updates on the same stream set and the smaller workgroups fill the gaps better)
+static const bool t_big_tiles = [] {
+    const char* e = getenv("NPW_QR_T_BIG");
+    return e != nullptr && atoi(e) != 0;
+}();
 static const bool near_kernels_on = [] {
     const char* e = getenv("NPW_QR_NEAR_KERNELS");
     return e == nullptr || atoi(e) != 0;
@@ -821,6 +831,7 @@ int apply_panel(const Batch& b, const double* Wp, int64_t ldv, int64_t mp, int64
     const bool big = pb >= 256 && whole_chip_of_big_tiles(b, pb, nc);   // a superblock reflector: the batch fills the chip with 128 x 128 tiles
     g1.force_big = big;
     int rc;
+    bool updated = false;
     if (near_kernels_on && pb <= PB && skws != nullptr && (size_t)pb * nc <= skcap) {
         // panel-wide reflector: the streaming kernels (per-slab partial products, one small kernel that reduces them in a
         // fixed order and applies T^T, the rank-pb update)
@@ -854,6 +865,21 @@ int apply_panel(const Batch& b, const double* Wp, int64_t ldv, int64_t mp, int64
         hipLaunchKernelGGL(reduce_tt_kernel<PB>, dim3((unsigned)ceil_div(nc, 16), (unsigned)b.count), dim3(PB * 16), 0, s, (int)pb, nc,
                            nsplit, skws, (const double*)nullptr, (int64_t)0, (int64_t)0, Tjj, ldt, b.sT, X2, sX2);
         NPW_LAUNCH_CHECK();
+    } else if (pb >= 256 && far_nt_form) {
+        // superblock reflector: the temporaries are kept TRANSPOSED (X^T = W2^T V, nc x pb), so that the rank-pb update reads
+        // both operands along k -- the N / T form, the only one with the pinned load / store interleave of gemm.hip
+        rc = gemm<double>('T', 'N', nc, pb, mp, 1.0, W2, ldv, Wp, ldv, 0.0, nullptr, 0, X1, pb, g1, s);
+        if (rc) return rc;
+        GemmOpts g2 = batched(b, sX1, b.sT, 0, sX2);
+        g2.force_big = big;
+        g2.b_lower_tri = true;   // T is upper triangular: column tile n0 of X1^T T only sums k < n0 + tile
+        rc = gemm<double>('N', 'N', nc, pb, pb, 1.0, X1, pb, Tjj, ldt, 0.0, nullptr, 0, X2, pb, g2, s);
+        if (rc) return rc;
+        GemmOpts g3 = batched(b, b.sV, sX2, b.sV, b.sV);
+        g3.force_big = whole_chip_of_big_tiles(b, mp, nc);
+        rc = gemm<double>('N', 'T', mp, nc, pb, -1.0, Wp, ldv, X2, pb, 1.0, W2, ldv, W2, ldv, g3, s);
+        if (rc) return rc;
+        updated = true;
     } else {
         rc = gemm<double>('T', 'N', pb, nc, mp, 1.0, Wp, ldv, W2, ldv, 0.0, nullptr, 0, X1, nc, g1, s);
         if (rc) return rc;
@@ -862,10 +888,12 @@ int apply_panel(const Batch& b, const double* Wp, int64_t ldv, int64_t mp, int64
         rc = gemm<double>('T', 'N', pb, nc, pb, 1.0, Tjj, ldt, X1, nc, 0.0, nullptr, 0, X2, nc, g2, s);
         if (rc) return rc;
     }
-    GemmOpts g3 = batched(b, b.sV, sX2, b.sV, b.sV);
-    g3.force_big = pb >= 256 && whole_chip_of_big_tiles(b, mp, nc);
-    rc = gemm<double>('N', 'N', mp, nc, pb, -1.0, Wp, ldv, X2, nc, 1.0, W2, ldv, W2, ldv, g3, s);
-    if (rc) return rc;
+    if (!updated) {
+        GemmOpts g3 = batched(b, b.sV, sX2, b.sV, b.sV);
+        g3.force_big = pb >= 256 && whole_chip_of_big_tiles(b, mp, nc);
+        rc = gemm<double>('N', 'N', mp, nc, pb, -1.0, Wp, ldv, X2, nc, 1.0, W2, ldv, W2, ldv, g3, s);
+        if (rc) return rc;
+    }
     if (Rdst == nullptr) return NPW_OK;
     const unsigned gy = (unsigned)(pb < 32 ? pb : 32);
     hipLaunchKernelGGL(move_rows_kernel, dim3((unsigned)ceil_div(nc, 256), gy, (unsigned)b.count), dim3(256), 0, s, (int)pb, nc,
@@ -1033,12 +1061,16 @@ int geqrt_core(const Batch& b_in, int64_t m, int64_t n, bool tri, double* V, int
             g1.splitk = (int)want;
             g1.splitk_ws = skws;
         }
+        const bool bigt = t_big_tiles && whole_chip_of_big_tiles(b, rows_out, w);
+        g1.force_big = bigt;
         int rc = gemm<double>('T', 'N', rows_out, w, kk, 1.0, Aop, ldv, Bop, ldv, 0.0, nullptr, 0, X1, w, g1, st);
         if (rc) return rc;
         GemmOpts g2 = batched(b, sX, b.sT, 0, sX);
+        g2.force_big = bigt;
         rc = gemm<double>('N', 'N', rows_out, w, w, 1.0, X1, w, Tq + c0 * ldtb + c0, ldtb, 0.0, nullptr, 0, X2, w, g2, st);
         if (rc) return rc;
         GemmOpts g3 = batched(b, b.sT, sX, 0, b.sT);
+        g3.force_big = bigt;
         g3.a_upper_tri = true;
         return gemm<double>('N', 'N', rows_out, w, rows_out, -1.0, Tq + r0 * ldtb + r0, ldtb, X2, w, 0.0, nullptr, 0,
                             Tq + r0 * ldtb + c0, ldtb, g3, st);

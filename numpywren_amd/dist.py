@@ -77,6 +77,8 @@ class RcclTransport(object):
     stream, ordered behind the producer by the tile's event and ahead of the consumers by the received tile's event.
     No torch tensors, no staging copies, no host synchronisation."""
     name = "rccl"
+    diag = False                          # True: every exchange is bracketed with timing events on the transport stream
+    _open = None                          # start event of the exchange being posted
 
     def __init__(self, rank, world, control):
         self.be = get_backend()          # binds this process to its device (LOCAL_RANK) before the communicator exists
@@ -98,9 +100,7 @@ class RcclTransport(object):
         self.rank, self.world = rank, world
         self._group = None                # open group: received tiles whose `ready` event is recorded at group end
         self._held = []                   # ... and the tiles being sent: alive until the launch has been enqueued
-        self.diag = False                 # True: every exchange is bracketed with timing events on the transport stream
-        self._spans = []                  # (start event, end event)
-        self._open = None
+        self._spans = []                  # diag: (start event, end event) of every exchange
 
     def begin_group(self):
         """Everything posted until end_group() leaves as ONE RCCL launch (ncclGroupStart / ncclGroupEnd): the sends and
@@ -123,6 +123,8 @@ class RcclTransport(object):
         if self._open is not None:
             ev = self.be.new_event(timing=True)
             self.be.record(ev, self.stream)
+            if not hasattr(self, "_spans"):
+                self._spans = []
             self._spans.append((self._open, ev))
             self._open = None
 
@@ -130,7 +132,7 @@ class RcclTransport(object):
         """Milliseconds of transport-stream time inside exchanges since the last call (synchronises the stream)."""
         self._span_end()
         total = 0.0
-        if self._spans:
+        if getattr(self, "_spans", None):
             self.be.stream_sync(self.stream)
             for a, b in self._spans:
                 total += self.be.elapsed_ms(a, b)

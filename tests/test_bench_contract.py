@@ -97,5 +97,15 @@ def test_bench_two_ranks_on_one_gpu(workload, extra, port):
     for k, t in REQUIRED.items():
         assert k in line and isinstance(line[k], t), k
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["transport"] == "host"
+    # every N > 1 line explains itself: per rank the host's walk, its blocked time, how far the device ran behind, the bytes
+    # moved (last timed step) and, from one extra step with executor.task_timers, device time by kernel and transport time
+    assert len(line["per_rank"]) == 2
+    for r, d in enumerate(line["per_rank"]):
+        t, x = d["timed_step"], d["diagnostic_step"]
+        assert t["rank"] == x["rank"] == r and t["transport"] == "host"
+        for key in ("host_walk_ms", "host_blocked_ms", "drain_ms", "bytes_sent", "bytes_received", "positions", "tasks_run_here"):
+            assert key in t and key in x, key
+        assert x["kernel_busy_ms"] > 0 and x["kernel_ms_by_name"] and x["transfer_wait_ms"] >= 0 and x["step_ms"] > 0
+    assert line["config"]["predicted"]["tflops_by_gpus"]["8"] > 0 and "not a measurement" in line["config"]["predicted"]["source"]
     if workload == "chol":
-        assert line["scaling"] == "strong" and line["config"]["bytes_sent_rank0"] > 0
+        assert line["scaling"] == "strong" and sum(d["timed_step"]["bytes_sent"] for d in line["per_rank"]) > 0

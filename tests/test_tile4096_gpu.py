@@ -175,7 +175,8 @@ def _run(program, **kw):
 def test_config1_cholesky_16384_full_residual(hbm_store):
     """BASELINE.json configs[1] as stated: 16384^2 fp64 Cholesky, 4096^2 tiles, through alg_wrappers.cholesky and the
     executor, with the FULL residual || A - L L^T ||_F / || A ||_F <= 1e-12 over all 16 tiles (on the device), the
-    reference's task count and zero strictly-upper output tiles."""
+    reference's task count and zero strictly-upper output tiles.  (The residual is formed with the build's own GEMM --
+    itself checked against the oracle on sampled rows of a 4096^3 product above -- not with an independent one.)"""
     import bench
     be = get_backend()
     nb = 4
@@ -357,6 +358,68 @@ def test_batched_launch_forms_4096_equal_single_launches():
         assert same(solved[i], be.trsm(L, Y[i]))
 
 
+@pytest.mark.parametrize("amplitude", [1.0, 0.25])
+def test_config1_reference_generator_zero_flag_path(amplitude, hbm_store):
+    """configs[1] with the EXPERIMENT's own generator (reference experiments/cholesky_experiment.py:78-92:
+    x x^T with lambdav = 20e12 N applied on every read of a diagonal tile) at the real tile size.  The panel tiles
+    L[j, i] = x_j x_i^T / sqrt(lambda) are around 1e-8 there, right at the threshold of kernels.syrk's allclose(x, 0)
+    short-circuit (reference kernels.py:213-214): with the generator as written (amplitude 1) every 4096^2 panel tile has
+    some entries above 1e-8 and NO update is skipped (small tiles of the same generator -- the 128^2 tiles of
+    test_algorithms_gpu -- are all below it); at a quarter of the amplitude every tile is below it and EVERY trailing
+    update returns its s unchanged.  The flags are raised on the device and flow into the skip arguments of the batched
+    launches without a host round trip.  Checked: every output tile against the oracle's run of the same DAG (sampled
+    rows), every device flag against np.allclose of the tile, and the short-circuit itself -- an update with a flagged
+    operand is its input, bit for bit."""
+    be = get_backend()
+    nb = 4
+    n = nb * B
+    np.random.seed(0)
+    x = amplitude * np.random.randn(n, 1)
+    lam = n * 20e12
+    xd = be.to_device(x.reshape(-1))
+    X = BigMatrix(f"t4096_sosp_{amplitude}", shape=(n, n), shard_sizes=(B, B), lambdav=lam)
+    for i in range(nb):
+        for j in range(i + 1):
+            X.put_tile(be.fill_outer((B, B), xd, i * B, j * B), i, j)
+    program, meta = alg_wrappers.cholesky(X)          # (no reclaim: the S versions are inspected below)
+    program.start()
+    res_run = job_runner.lambdapack_run(program, timeout=600)
+    program.wait()
+    assert program.program_status() == lp.PS.SUCCESS, program.exceptions
+    assert len(res_run["executed_messages"]) == 20
+    O, S = meta["outputs"][0], meta["intermediates"][0]
+    A = x @ x.T
+    ref = oracle.cholesky(A, B, lambdav=lam)
+    rows = np.random.default_rng(1).choice(B, size=64, replace=False)
+    zero = {}
+    for i in range(nb):
+        for j in range(i + 1):
+            full = be.to_host(O.get_tile(i, j))
+            want = ref[i * B:(i + 1) * B, j * B:(j + 1) * B][rows]
+            np.testing.assert_allclose(full[rows], want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
+            if i > j:
+                # a panel tile: the device's flag is the reference's test (allclose with its default atol 1e-8)
+                zero[(i, j)] = bool(np.allclose(full, 0))
+                assert bool(be.read_flag(be.zero_flag(O.get_tile(i, j)))) == zero[(i, j)]      # (flags are preset to non-zero and cleared)
+    # the generator as written: every 4096^2 panel tile has a few entries above the threshold (the largest |x_r x_c| of 16 M
+    # pairs over sqrt(lambda) is ~2e-8), so no update is skipped; at a quarter of the amplitude every one is
+    assert all(zero.values()) if amplitude < 1.0 else not any(zero.values())
+    # S[i+1, j, k] = syrk(S[i, j, k], O[j, i], O[k, i]) returned s itself wherever one operand was flagged ...
+    def version(i, j, k):
+        if i == 0:          # the input tile, with the shift get_block applies on a diagonal read (matrix.py:307-309)
+            t = A[j * B:(j + 1) * B, k * B:(k + 1) * B][rows].copy()
+            if j == k:
+                t[np.arange(64), rows] += lam
+            return t
+        return be.to_host(S.get_tile(i, j, k))[rows]
+    for (i, j, k) in [(0, 2, 1), (0, 1, 1), (1, 3, 2), (0, 3, 3), (1, 3, 3)]:
+        skipped = zero[(j, i)] or (k != j and zero[(k, i)])
+        same = np.array_equal(version(i + 1, j, k), version(i, j, k))
+        assert same == skipped, (i, j, k, skipped)
+    program.free()
+    X.free()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # BASELINE.json configs[2] / [3] / [4] at their FULL size on the one GPU of the test box (VERDICT r2 item 1): the
 # 65536^2 Cholesky, the 256-leaf TSQR (1048576 x 4096) and the 32768^2 fp32 GEMM program all fit 288 GB of HBM.
@@ -366,7 +429,8 @@ def test_batched_launch_forms_4096_equal_single_launches():
 # ---------------------------------------------------------------------------------------------------------------
 def test_config2_cholesky_65536_full_residual(hbm_store):
     """configs[2]'s matrix on one GPU: 65536^2 fp64, 4096^2 tiles, 816 tasks (the reference's count), and the FULL
-    residual || A - L L^T ||_F / || A ||_F over all 136 lower tiles <= 1e-12, computed on the device."""
+    residual || A - L L^T ||_F / || A ||_F over all 136 lower tiles <= 1e-12, computed on the device with the build's
+    own GEMM (bench.cholesky_residual -> be.gemm: oracle-checked at 4096^2 in this file, not an independent product)."""
     import bench
     be = get_backend()
     nb = 16
@@ -408,7 +472,8 @@ def _gram(be, X, leaves):
 def test_config3_tsqr_256_leaves_r_only(hbm_store):
     """configs[3]'s input on one GPU: 1048576 x 4096 fp64, 256 leaves, 511 tasks.  With `reclaim_intermediates` +
     `drop_unread_outputs` the V / T factors (which no task reads; ~290 GB) are dropped as they are stored -- the
-    R-only form bench.py times on fewer than 4 GPUs; R^T R = A^T A to 1e-11."""
+    R-only form bench.py reports beside its V / T-keeping run; R^T R = A^T A to 1e-11, both Gram
+    matrices formed with the build's own GEMM (oracle-checked at 4096^2 in this file)."""
     be = get_backend()
     leaves = 256
     X = _tsqr_input(be, leaves, "t4096_tsqr256")
@@ -431,19 +496,21 @@ def test_config3_tsqr_256_leaves_r_only(hbm_store):
     X.free()
 
 
-def test_config3_tsqr_64_leaves_keeps_v_t(hbm_store):
-    """The same program keeping what the reference's wrapper returns (alg_wrappers.py:47: [R, V, T]): 64 leaves, every
-    V / T tile stays in HBM; the top node's factors reproduce its operands, (I - V T V^T) [R; 0] = [R_left; R_right]
-    to 1e-13, a leaf's reproduce its input tile, and R^T R = A^T A."""
+@pytest.mark.parametrize("leaves", [64, 256])
+def test_config3_tsqr_keeps_v_t(leaves, hbm_store):
+    """The same program keeping what the reference's wrapper returns (alg_wrappers.py:47: [R, V, T]): every V / T tile
+    stays in HBM -- at 256 leaves configs[3]'s full input with its full output set, 160 GiB of factors on the one GPU
+    (round 4: the factorisations share one scratch buffer per stream); the top node's factors reproduce its operands,
+    (I - V T V^T) [R; 0] = [R_left; R_right] to 1e-13, a leaf's reproduce its input tile, and R^T R = A^T A (residuals
+    formed with the build's own GEMM)."""
     be = get_backend()
-    leaves = 64
-    X = _tsqr_input(be, leaves, "t4096_tsqr64")
+    X = _tsqr_input(be, leaves, f"t4096_tsqr{leaves}_vt")
     program, meta = alg_wrappers.tsqr(X)
     program.config["executor"]["reclaim_intermediates"] = True      # on its own this no longer drops V / T
-    _run(program, pipeline_width=2)
+    _run(program, pipeline_width=2 if leaves <= 64 else 1)
     assert program.program_status() == lp.PS.SUCCESS, program.exceptions
     Rs, Vs, Ts = meta["outputs"]
-    top = 6
+    top = int(np.log2(leaves))
     assert all(Vs.tile_exists(0, j) and Ts.tile_exists(0, j) for j in range(leaves))
     assert all(Vs.tile_exists(lv, 0) and Ts.tile_exists(lv, 0) for lv in range(1, top + 1))
     R = Rs.get_tile(top, 0)
@@ -465,7 +532,7 @@ def test_config3_tsqr_64_leaves_keeps_v_t(hbm_store):
 
     V, T = Vs.get_tile(top, 0), Ts.get_tile(top, 0)
     assert V.shape == (2 * B, B) and T.shape == (B, B)
-    assert reconstruct(V, T, R, [Rs.get_tile(top - 1, 0), Rs.get_tile(top - 1, 32)]) < 1e-13
+    assert reconstruct(V, T, R, [Rs.get_tile(top - 1, 0), Rs.get_tile(top - 1, leaves // 2)]) < 1e-13
     assert reconstruct(Vs.get_tile(0, 17), Ts.get_tile(0, 17), Rs.get_tile(0, 17), [X.get_tile(17, 0)]) < 1e-13
     program.free()
     X.free()

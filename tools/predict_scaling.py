@@ -17,7 +17,7 @@ configs[2], 65536^2 Cholesky (16 x 16 tiles of 4096^2, 816 tasks): a list-schedu
     the N > 1 rows the times of the 3-stream, no-chain-partition configuration those ranks run (`bench.py --streams 3`:
     a chol there is fenced -- it gets the chip -- but the batched launches are shorter because tasks become ready one by one).
 configs[3], 1048576 x 4096 TSQR (256 leaves): per GPU the leaf batches and the local tree levels at the measured batched
-  times (tools/qr_soak.py, tools/tpqrt_time.py: with T from 4 GPUs on, where V / T fit; R only below), then log2(N) levels
+  times (tools/qr_soak.py, tools/tpqrt_time.py, with T: bench.py keeps R, V, T on any number of GPUs), then log2(N) levels
   of one 128 MiB R factor over one link + one single-node factorisation each.
 configs[4], 32768^2 fp32 GEMM program (8 x 8 x 8 tiles): C tiles 2-D block-cyclic, the prologue's A / B panel pushes as one
   all-to-all-v (bytes of the busiest directed link / link rate; products start as their operands arrive, so the run is the
@@ -154,7 +154,7 @@ def simulate_cholesky(world, nb, link_gbs, kernel_ms, host_us):
 
 
 def predict_tsqr(world, leaves, link_gbs):
-    keep_vt = world >= 4                       # bench.py: V / T are kept where they fit
+    keep_vt = True                             # bench.py: R, V, T -- the reference's outputs -- on any number of GPUs
     per = leaves // world
     ms = batched_ms(GEQRT_MS[keep_vt], per)
     nodes = per // 2
