@@ -15,6 +15,7 @@
 //   T off-diagonal blocks bottom-up:  T12 = -T1 * (V1^T V2) * T2 with V^T V from one big GEMM.
 #include "npw_internal.h"
 
+#include <algorithm>
 #include <atomic>
 #include <type_traits>
 #include <chrono>
@@ -989,6 +990,15 @@ int geqrt_core(const Batch& b_in, int64_t m, int64_t n, bool tri, double* V, int
                int64_t ldr, void* workspace, hipStream_t s) {
     const QrWorkspace q = carve(workspace, m, n, b_in.count, b_in.count);
     double* const Vlow = V + n * ldv;  // tri: the lower block
+    {
+        // every workgroup of a panel launch waits for the others: the whole launch has to be resident on the stream's CUs
+        // (a CU-masked stream of the executor offers fewer than the chip: refuse instead of timing out with wrong numbers)
+        const int64_t slots = 2 * (int64_t)stream_cu_count(s);
+        const int64_t rows_max = tri ? n + PB : m;
+        const int64_t need = (int64_t)b_in.count * ceil_div(rows_max, 2 * SLAB);
+        NPW_REQUIRE(need <= slots, "batched QR: %lld x %lld rows need %lld resident panel workgroups, the stream's %d compute "
+                    "units hold %lld", (long long)b_in.count, (long long)rows_max, (long long)need, stream_cu_count(s), (long long)slots);
+    }
     // (small batches are bound by the latency of the panel chain, not by GEMM throughput: the extra launches and waits of
     //  the third level cost them time -- 4096^2: x1 17.6 ms without it, 19.9 / 27 ms with SB = 256 / 128; x4 26.3 vs 29.0)
     const int64_t SB = b_in.count >= 8 ? superblock_width(tri) : ((n + OB - 1) / OB) * OB;
@@ -1039,6 +1049,11 @@ int geqrt_core(const Batch& b_in, int64_t m, int64_t n, bool tri, double* V, int
         NPW_HIP_CHECK(hipEventRecord(side->join, s));  // so that the closing wait is valid for a single block
     }
     hipStream_t far = side->stream3;
+    static const int64_t panel_wgs_env = [] {
+        const char* e = getenv("NPW_QR_PANEL_MAX_WGS");
+        return e ? (int64_t)atoll(e) : (int64_t)PANEL_MAX_WGS;
+    }();
+    const int64_t panel_max_wgs = std::min<int64_t>(panel_wgs_env, 2 * (int64_t)stream_cu_count(s));   // (default: half of the chip's slots)
     bool far_in_flight = false;   // a far update has been issued: the next `mid` update waits for its first part
 
     // T[r0:c0, c0:c0+w] = -T[r0:c0, r0:c0] * (V[:, r0:c0]^T V[:, c0:c0+w]) * T[c0:c0+w, c0:c0+w]   (DLARFT's recurrence for a
@@ -1189,7 +1204,7 @@ int geqrt_core(const Batch& b_in, int64_t m, int64_t n, bool tri, double* V, int
             // every workgroup of the launch has to be resident: beyond a quarter of the chip's slots per launch (two
             // workgroups fit a CU, two batches may run side by side on two streams of the executor, the far updates' GEMM
             // workgroups hold slots as well) a slab takes two rows per thread
-            const int rpt = (b.count * ceil_div(mp, SLAB) > PANEL_MAX_WGS) ? 2 : 1;
+            const int rpt = (b.count * ceil_div(mp, SLAB) > panel_max_wgs) ? 2 : 1;
             const int G = (int)ceil_div(mp, SLAB * rpt);
             hipLaunchKernelGGL(rpt == 2 ? qr_panel3_kernel<2> : qr_panel3_kernel<1>, dim3(G, b.count), dim3(SLAB), 0, s, (int)mp, (int)pb, Wp, ldv,
                                Tq + j0 * ldtb + j0, ldtb, R + j0 * ldr + j0, ldr, reinterpret_cast<slot_t*>(q.Part),

@@ -37,10 +37,26 @@ int side_stream(hipStream_t main, SideStream** out) {
     static thread_local std::unordered_map<hipStream_t, SideStream> table;
     SideStream& e = table[main];
     if (e.stream == nullptr) {
-        NPW_HIP_CHECK(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
+        // A caller's stream restricted to some compute units (npw_stream_create_masked: the executor's partitions) gets
+        // helpers with the SAME mask: what a call forks off must not spill onto the CUs its stream was kept away from.
+        const int cus = device_cu_count();
+        const uint32_t words = (uint32_t)((cus + 31) / 32);
+        uint32_t mask[16] = {0};
+        bool masked = false;
+        if (main != nullptr && words <= 16 && hipExtStreamGetCUMask(main, words, mask) == hipSuccess) {
+            int bits = 0;
+            for (uint32_t w = 0; w < words; ++w) bits += __builtin_popcount(mask[w]);
+            masked = bits > 0 && bits < cus;
+        } else {
+            (void)hipGetLastError();
+        }
+        auto make = [&](hipStream_t* out) -> hipError_t {
+            return masked ? hipExtStreamCreateWithCUMask(out, words, mask) : hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+        };
+        NPW_HIP_CHECK(make(&e.stream));
         NPW_HIP_CHECK(hipEventCreateWithFlags(&e.fork, hipEventDisableTiming));
         NPW_HIP_CHECK(hipEventCreateWithFlags(&e.join, hipEventDisableTiming));
-        NPW_HIP_CHECK(hipStreamCreateWithFlags(&e.stream2, hipStreamNonBlocking));
+        NPW_HIP_CHECK(make(&e.stream2));
         NPW_HIP_CHECK(hipEventCreateWithFlags(&e.fork2, hipEventDisableTiming));
         NPW_HIP_CHECK(hipEventCreateWithFlags(&e.join2, hipEventDisableTiming));
         // the throughput helper: optionally kept off the leading `reserve` bits of the CU mask (the bits are dealt
@@ -50,13 +66,12 @@ int side_stream(hipStream_t main, SideStream** out) {
             const char* v = getenv("NPW_QR_FAR_RESERVE_CUS");
             return v ? atoi(v) : 0;
         }();
-        const int cus = device_cu_count();
-        if (reserve > 0 && reserve < cus && cus <= 512) {
-            uint32_t mask[16] = {0};
-            for (int cu = reserve; cu < cus; ++cu) mask[cu / 32] |= 1u << (cu % 32);
-            NPW_HIP_CHECK(hipExtStreamCreateWithCUMask(&e.stream3, (uint32_t)((cus + 31) / 32), mask));
+        if (!masked && reserve > 0 && reserve < cus && cus <= 512) {
+            uint32_t rest[16] = {0};
+            for (int cu = reserve; cu < cus; ++cu) rest[cu / 32] |= 1u << (cu % 32);
+            NPW_HIP_CHECK(hipExtStreamCreateWithCUMask(&e.stream3, words, rest));
         } else {
-            NPW_HIP_CHECK(hipStreamCreateWithFlags(&e.stream3, hipStreamNonBlocking));
+            NPW_HIP_CHECK(make(&e.stream3));
         }
         NPW_HIP_CHECK(hipEventCreateWithFlags(&e.fork3, hipEventDisableTiming));
         NPW_HIP_CHECK(hipEventCreateWithFlags(&e.join3, hipEventDisableTiming));
