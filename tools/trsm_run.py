@@ -11,3 +11,9 @@ for rep in range(4):
     be.synchronize(); t0 = time.time()
     X = be.trsm(L, Y)
     be.synchronize(); print("trsm ms", 1e3 * (time.time() - t0))
+# the batched form (the right-hand sides of one block column: 3 at step 0 of configs[1])
+Ys = [be.fill_random((n, n), seed=20 + i) for i in range(3)]
+for rep in range(4):
+    be.synchronize(); t0 = time.time()
+    Xs = be.trsm_batched(L, Ys, exact_zero=False)
+    be.synchronize(); print("trsm_batched x3 ms", 1e3 * (time.time() - t0))
