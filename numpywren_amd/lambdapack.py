@@ -408,6 +408,7 @@ class LambdaPackProgram(object):
             self._ready = []
             self._finished_terminators = set()
             self._success_pending = False
+            self.info_flags = []       # (deferred LinAlgError flags of an abandoned run must not fail this one)
         # no worker has been up yet (wait() tells "not started" from "worker gone" by this), and partial sums of an
         # aborted fused-GEMM run (job_runner.ReductionFusion) must not be accumulated into
         self._was_up = False
