@@ -150,12 +150,13 @@ def test_qr_factor_4096_vs_dgeqrt(stack):
     m = B * len(args)
     assert V.shape == (m, B) and T.shape == (B, B) and R.shape == (B, B)
     # Householder QR is backward stable, but V, T, R individually move with the conditioning of the leading column
-    # blocks (the last reflectors of a square Gaussian tile act on tiny Schur complements): element-wise agreement
-    # with LAPACK to 1e-8 of each factor's scale catches any structural error; the PRECISION is checked through the
-    # identities below, which hold to 1e-13.
-    np.testing.assert_allclose(R, Rr, rtol=0, atol=1e-9 * np.abs(Rr).max())
-    np.testing.assert_allclose(V, Vr, rtol=0, atol=1e-8)
-    np.testing.assert_allclose(T, Tr, rtol=0, atol=1e-8 * np.abs(Tr).max())
+    # blocks (the last reflectors of a square Gaussian tile act on tiny Schur complements; cond ~ 4e4 for this one).
+    # Measured against LAPACK (tools/qr_dev_vs_lapack.py, round 4): R 2.9e-15 of its scale, V 9.6e-14, T 9.7e-14 of its
+    # scale for the square tile, 2 - 6e-16 for the well-conditioned stack: the bounds below leave two orders of magnitude
+    # (round 3 compared at 1e-8: VERDICT r3, "loosest oracle comparison in the suite").
+    np.testing.assert_allclose(R, Rr, rtol=0, atol=1e-12 * np.abs(Rr).max())
+    np.testing.assert_allclose(V, Vr, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(T, Tr, rtol=0, atol=1e-11 * np.abs(Tr).max())
     assert not np.tril(R, -1).any() and not np.triu(V, 1).any() and np.all(np.diag(V) == 1) and not np.tril(T, -1).any()
     A = np.vstack(args)
     G = A.T @ A
