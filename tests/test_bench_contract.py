@@ -62,6 +62,21 @@ def test_bench_other_configs(workload, extra):
     assert line["value"] > 0 and line["dtype"] == ("f64" if workload == "tsqr" else "f32")
 
 
+def test_predicted_scaling_table_is_the_one_bench_quotes():
+    """profiles/predicted_scaling.json (tools/predict_scaling.py) is the single source of the predicted 1 / 2 / 4 / 8-GPU
+    figures: bench.py's N > 1 lines read it, and it covers the three multi-GPU workloads of BASELINE.json."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for workload in ("chol", "tsqr", "gemm32"):
+        p = bench._predicted_scaling(workload)
+        assert p is not None and "not a measurement" in p["source"]
+        t = p["tflops_by_gpus"]
+        assert set(t) == {"1", "2", "4", "8"} and t["1"] < t["2"] < t["4"] < t["8"]
+        assert all(r["gpus"] in (1, 2, 4, 8) and r["ms"] > 0 for r in p["rows"])
+    per_tile, src = bench._syrk_traffic()
+    assert src.startswith("profiles/r") and 5.37e8 < per_tile < 1e10      # PMC passes of the newest round, above the algorithmic bytes
+
+
 @pytest.mark.gpu
 def test_bench_distributed_path_on_one_gpu():
     """The N > 1 code path of bench.py (dist.init_process_group -> RCCL transport -> lambdapack_run_distributed) with a
