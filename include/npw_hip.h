@@ -248,6 +248,13 @@ int npw_dtpqrt_batched(int count, int64_t n, const double* const* A1, const doub
                        int64_t stride_t, double* R, int64_t ldr, int64_t stride_r, void* workspace,
                        npw_stream_t stream);
 
+/* The QR panel kernel's workgroups hand partial sums to one another through tagged slots and wait for them with a BOUNDED
+ * spin (a lost hand-off must not hang the GPU).  A wait that expires leaves that call's V / T / R undefined; this returns how
+ * many lanes' waits have expired since the last reset (0 in every correct run) so that the caller can fail loudly -- the
+ * executor raises when a run with qr_factor / lq_factor tasks settles with a non-zero count.  Blocks until the copy of the
+ * 4-byte counter is done (not a stream operation); reset != 0 clears it. */
+int npw_dgeqrt_handoff_timeouts(int* count, int reset);
+
 /* out = sum_i in[i]   (count operands of rows x cols each; fp64 accumulate/output).
  * in_is_f32[i] != 0 marks a float32 operand (the reference's add_matrices always
  * produces float64: np.zeros(args[0].shape) += a).  in pointers are HOST arrays of

@@ -79,6 +79,7 @@ PROTOTYPES = {
     "npw_dpotrf_lower_blocks": (c_int, [_i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "npw_dtrtri_complete": (c_int, [_i64, _vp, _i64, _vp, _vp]),
     "npw_dgeqrt_workspace_bytes": (_sz, [_i64, _i64]),
+    "npw_dgeqrt_handoff_timeouts": (c_int, [POINTER(c_int), c_int]),
     "npw_dgeqrt": (c_int, [_i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "npw_dtpqrt_batched_workspace_bytes": (_sz, [c_int, _i64]),
     "npw_dtpqrt_batched": (c_int, [c_int, _i64, POINTER(_vp), POINTER(_vp), _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64,

@@ -96,6 +96,11 @@ __device__ long long qr_stamps[8];
 // synchronisation (no counter, no fence, no separate barrier; one memory hop per column instead of three).
 typedef double slot_t __attribute__((ext_vector_type(2)));  // {value, tag bits}
 
+// Lanes whose bounded wait for a hand-off slot expired since the last reset.  A lost hand-off leaves the call's results
+// undefined (the wait is bounded so that it cannot hang the GPU); the count is what lets the host fail loudly instead of
+// returning them (npw_dgeqrt_handoff_timeouts; the executor checks it when a run with QR tasks settles).
+__device__ int qr_handoff_timeouts = 0;
+
 // (The trailing s_nop: a store of more than 8 bytes keeps reading its data registers for a wait state or two after
 // issue; the compiler pads its own stores against a following VALU write of those registers but cannot see into the
 // asm -- without the padding lanes 12..15 of every 16 stored the NEXT slot's contents when stores followed each other.)
@@ -152,6 +157,7 @@ __device__ inline void ld_slots4(const slot_t* p0, const slot_t* p1, const slot_
         else
             __builtin_amdgcn_s_sleep(8);
     }
+    atomicAdd(&qr_handoff_timeouts, 1);   // expired: the values returned above are not the ones waited for
 }
 
 // ---- wave-level reduce-scatter of 32 per-lane values over the 64 lanes of a wave ---------------------------------
@@ -1456,6 +1462,16 @@ int npw_dtpqrt_batched(int count, int64_t n, const double* const* A1, const doub
     b.sT = stride_t;
     b.sR = stride_r;
     return geqrt_core(b, 2 * n, n, true, V, ldv, T, ldt, R, ldr, workspace, s);
+}
+
+int npw_dgeqrt_handoff_timeouts(int* count, int reset) {
+    NPW_REQUIRE(count != nullptr, "npw_dgeqrt_handoff_timeouts: NULL");
+    NPW_HIP_CHECK(hipMemcpyFromSymbol(count, HIP_SYMBOL(qr_handoff_timeouts), sizeof(int)));
+    if (reset && *count != 0) {
+        const int zero = 0;
+        NPW_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(qr_handoff_timeouts), &zero, sizeof(int)));
+    }
+    return NPW_OK;
 }
 
 #ifdef NPW_QR_STAMPS

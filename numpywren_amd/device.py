@@ -1302,6 +1302,13 @@ class HipBackend(object):
             r.upper = True
         return out
 
+    def qr_handoff_timeouts(self, reset=True):
+        """Expired hand-off waits inside the QR panel kernel since the last reset (npw_dgeqrt_handoff_timeouts): 0 in
+        every correct run; anything else means a factorisation returned undefined numbers."""
+        n = ctypes.c_int(0)
+        _ffi.check(self.lib.npw_dgeqrt_handoff_timeouts(ctypes.byref(n), 1 if reset else 0), "qr_handoff_timeouts")
+        return n.value
+
     def gebd2(self, A, stream=None):
         """(d, e) of the upper bidiagonal form of the square fp64 tile A (npw_dgebd2; A is not modified)."""
         self._require_2d(A, "banded_to_bidiagonal")

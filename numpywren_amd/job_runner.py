@@ -585,6 +585,21 @@ def collect_task_times(program):
     return out
 
 
+def check_handoffs(program, be):
+    """A run with Householder factorisations: did a hand-off wait inside the panel kernel expire (libnpw_hip.so bounds them
+    so that a lost hand-off cannot hang the GPU)?  Then some factorisation returned undefined numbers: fail the program."""
+    kinds = getattr(program.program, "_kernels", {}) or {}
+    if not hasattr(be, "qr_handoff_timeouts") or not any(getattr(k, "_npw_handoff", False) for k in kinds.values()):
+        return True
+    lost = be.qr_handoff_timeouts(reset=True)
+    if lost:
+        program.handle_exception(RuntimeError("{0} hand-off waits of the QR panel kernel expired during this run: the "
+                                              "factorisations' results are undefined".format(lost)),
+                                 tb="", expr_idx=-1, var_values={})
+        return False
+    return True
+
+
 def check_info_flags(program, be, stream=None):
     """Deferred np.linalg.LinAlgError: read back the Cholesky info flags of the run (the caller has synchronised with
     their producers; `stream` only carries the copies)."""
@@ -755,13 +770,13 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
             try:
                 if marks is None or wait:
                     be.synchronize()
-                    ok = check_info_flags(program, be)
+                    ok = check_info_flags(program, be) and check_handoffs(program, be)
                     for ev in (marks or []):
                         be.recycle_event(ev)
                 else:
                     for ev in marks:
                         be.event_sync(ev)   # (events stay alive: a later run may still be told to wait for them)
-                    ok = check_info_flags(program, be, be.flag_stream())
+                    ok = check_info_flags(program, be, be.flag_stream()) and check_handoffs(program, be)
                 program._defer_success = False
                 if ok and program._success_pending and program.program_status() == lp.PS.RUNNING:
                     program.return_success()

@@ -472,6 +472,8 @@ lq_trailing_update.flops = _qr_trailing_flops
 
 # panel kernels sit on the critical path of the factorizations and are latency-bound: the executor
 # issues them on its high-priority stream so they overtake queued trailing updates
+for _k in (qr_factor, lq_factor):
+    _k._npw_handoff = True   # runs the panel kernel: the executor checks its expired-wait counter when the run settles
 for _k in (chol, trsm, qr_factor, lq_factor):
     _k._npw_latency_bound = True
 chol._npw_needs_whole_cus = True   # see job_runner.LambdaPackExecutor.run_task
@@ -538,6 +540,7 @@ def _qr_factor_triangular_batch(be, stream, arg_lists, kwargs_list):
 
 
 qr_factor_triangular._npw_batch = _qr_factor_triangular_batch
+qr_factor_triangular._npw_handoff = True
 qr_factor_triangular._npw_needs_whole_cus = True
 
 

@@ -393,6 +393,37 @@ def test_restart_after_an_aborted_fused_run_starts_from_clean_sums(oracle_backen
     np.testing.assert_allclose(meta["outputs"][0].numpy(), C, rtol=1e-12, atol=1e-12)
 
 
+def test_expired_qr_handoffs_fail_the_program(oracle_backend):
+    """The QR panel kernel bounds its waits for hand-off slots (a lost hand-off must not hang the GPU); libnpw_hip.so counts the
+    waits that expired and the executor reads the count when a run with qr_factor tasks settles: non-zero fails the program
+    loudly instead of returning undefined factors.  (Here the checker backend plays a device that lost three.)"""
+    Xh = ALG["tsqr_64_8/X"]
+    X = BigMatrix("tsqr_handoff", shape=Xh.shape, shard_sizes=(8, Xh.shape[1]))
+    shard_matrix(X, Xh)
+    asked = []
+    oracle_backend.qr_handoff_timeouts = lambda reset=True: (asked.append(reset), 3)[1]
+    try:
+        program, meta = alg_wrappers.tsqr(X)
+        program.start()
+        job_runner.lambdapack_run(program)
+        program.wait()
+    finally:
+        del oracle_backend.qr_handoff_timeouts
+    assert asked == [True] and program.program_status() == lp.PS.EXCEPTION
+    assert any("hand-off" in str(v) for v in program.exceptions.values())
+    # a program without Householder factorisations never asks
+    A = ALG["cholesky_32_8/A"]
+    Xc = BigMatrix("handoff_chol", shape=A.shape, shard_sizes=(8, 8))
+    shard_matrix(Xc, A)
+    oracle_backend.qr_handoff_timeouts = lambda reset=True: (asked.append(reset), 3)[1]
+    try:
+        program, meta = alg_wrappers.cholesky(Xc)
+        run(program)
+    finally:
+        del oracle_backend.qr_handoff_timeouts
+    assert asked == [True] and program.program_status() == lp.PS.SUCCESS
+
+
 def test_fusion_leaves_other_programs_alone(oracle_backend):
     """Nothing fuses in a program without the gemm -> add_matrices pattern; a Temp tile with a second reader would not
     fuse either (the DAG decides, not the program's name)."""

@@ -301,6 +301,7 @@ def test_qr_r_only_form_gives_the_same_v_and_r(m, n, count, tri):
     with kernels.stream_scope(None, None, True, unwanted=[{0, 1}]):
         v, t, r = kernels.qr_factor(a)
     assert t is None and np.array_equal(r, kernels.qr_factor(a)[2])
+    assert be.qr_handoff_timeouts() == 0          # no wait for a hand-off slot expired (npw_dgeqrt_handoff_timeouts)
 
 
 @pytest.mark.parametrize("n,count", [(8, 1), (32, 2), (40, 3), (96, 1), (128, 4), (200, 2), (512, 3), (1024, 2), (1024, 9),

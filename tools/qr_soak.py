@@ -35,3 +35,4 @@ ts = np.array(times) * 1e3
 print(f"geqrt x{cnt} {m}x{n}{'' if WANT_T else ' (R only)'}, {reps} reps: median {np.median(ts):.2f} ms ({np.median(ts) / cnt:.2f} per tile), min {ts.min():.2f}, "
       f"max {ts.max():.2f}; worst |R^T R - A^T A| / |A^T A| = {worst:.2e}")
 print("all:", " ".join(f"{t:.1f}" for t in ts))
+print("expired hand-off waits:", be.qr_handoff_timeouts())
