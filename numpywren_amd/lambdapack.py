@@ -294,8 +294,15 @@ class LambdaPackProgram(object):
 
     # ---- keys (same string forms as the reference, lambdapack.py:507-519) ----
     def _node_str(self, expr_idx, var_values):
-        var_strs = sorted(["{0}:{1}".format(key, value) for key, value in var_values.items()])
-        return "{0}_({1})".format(expr_idx, "-".join(var_strs))
+        # (memoised: the walk asks for a node's string several times per task -- a quarter of its host time.  The key
+        #  keeps the dict's own item order, so two orders of one node are two entries with the same string.)
+        ck = (expr_idx, tuple(var_values.items()))
+        cache = self.__dict__.setdefault("_nstr_cache", {})
+        out = cache.get(ck)
+        if out is None:
+            var_strs = sorted(["{0}:{1}".format(key, value) for key, value in var_values.items()])
+            out = cache[ck] = "{0}_({1})".format(expr_idx, "-".join(var_strs))
+        return out
 
     def _node_key(self, expr_idx, var_values):
         return "{0}_{1}".format(self.hash, self._node_str(expr_idx, var_values))
@@ -431,19 +438,26 @@ class LambdaPackProgram(object):
         are all done, count terminators (reference lambdapack.py:545-639)."""
         try:
             post_op_start = time.time()
-            children = self.program.find_children(expr_idx, var_values)
+            task_of = getattr(self.program, "task", None)
+            if task_of is not None:     # the expanded DAG: children and their parent counts without further look-ups
+                kids = task_of(expr_idx, var_values).children
+                children = [c.node for c in kids]
+                nparents = [len(c.parents) for c in kids]
+            else:
+                children = self.program.find_children(expr_idx, var_values)
+                nparents = None
             self.set_node_status(expr_idx, var_values, NS.POST_OP)
             if ret_code == PS.EXCEPTION and tb is not None:
                 self.handle_exception(" EXCEPTION", tb=tb, expr_idx=expr_idx, var_values=var_values)
             me = self._node_str(expr_idx, var_values)
             ready_children = []
-            for child in children:
+            for ci, child in enumerate(children):
                 ckey = self._node_str(*child)
                 with self._lock:
                     edges = self._edges.setdefault(ckey, set())
                     edges.add(me)  # idempotent: a replayed task never double counts
                     val = len(edges)
-                num_child_parents = len(self.program.find_parents(child[0], child[1]))
+                num_child_parents = nparents[ci] if nparents is not None else len(self.program.find_parents(child[0], child[1]))
                 if val == num_child_parents and self.get_node_status(*child) not in (NS.FINISHED, NS.READY,
                                                                                       NS.RUNNING, NS.POST_OP):
                     self.set_node_status(child[0], child[1], NS.READY)

@@ -60,8 +60,19 @@ OBJECTS = _ObjectTable()
 RESIDENCY = Residency(OBJECTS)   # which stored tiles are in HBM, which in pinned host DRAM (residency.py)
 
 
+_FILE_TIER = {}
+
+
 def _store_tier():
-    return _config.default()["store"]["tier"]
+    """config.default()["store"]["tier"] without building the whole configuration for every stored tile: the environment
+    override is looked up each time (tests switch it), the file's / default value once per configuration file."""
+    tier = os.environ.get("NUMPYWREN_AMD_STORE")
+    if tier:
+        return tier
+    path = os.environ.get("NUMPYWREN_AMD_CONFIG_FILE")
+    if path not in _FILE_TIER:
+        _FILE_TIER[path] = _config.default()["store"]["tier"]
+    return _FILE_TIER[path]
 
 
 class BigMatrix(object):

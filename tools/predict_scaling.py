@@ -7,7 +7,7 @@ section 6 and BASELINE.md quote.      python tools/predict_scaling.py [--link-gb
 configs[2], 65536^2 Cholesky (16 x 16 tiles of 4096^2, 816 tasks): a list-scheduling simulation of numpywren_amd/dist.py:
   * the common task sequence = LambdaPackProgram's ready heap (critical-path priority), children released when their
     parents have been issued; EVERY rank walks every position of it on the host (`--host-us`, measured by
-    tools/host_walk_cost.py: 0.14 ms per position on 8 gloo ranks) and can only enqueue a task once its walk has reached it;
+    tools/host_walk_cost.py: 0.10 ms per position on 8 gloo ranks) and can only enqueue a task once its walk has reached it;
   * tile ownership 2-D block-cyclic on the Pr x Pc grid, owner computes; a GPU runs one chip-filling kernel at a time and
     picks, among its tasks whose inputs have arrived, the earliest in the common sequence (3 executor streams);
   * a produced tile is pushed to every GPU owning a consumer: 128 MiB per destination, one xGMI link per pair of GPUs,
@@ -38,7 +38,7 @@ os.environ["NUMPYWREN_AMD_STORE"] = "host"
 # ---- measured single-GPU inputs (ms); sources in profiles/r04_*.md ----------------------------------------------------
 KERNEL_MS_1GPU = {"chol": 1.48, "trsm": 1.10, "syrk": 1.89, "syrk_sym": 1.08}          # one stream + chain partition
 KERNEL_MS_3STREAMS = {k: round(v * 1359.4 / 1343.5, 4) for k, v in KERNEL_MS_1GPU.items()}   # bench.py --tiles 16 --streams 3: 1359.4 ms against 1343.5 (gpurun_out/r04l): every kind scaled by that ratio
-HOST_US_PER_POSITION = 140.0                                                            # tools/host_walk_cost.py
+HOST_US_PER_POSITION = 101.0                                                            # tools/host_walk_cost.py (0.140 before the walk was trimmed in round 4)
 TILE_BYTES = 4096 * 4096 * 8
 # batched QR of 4096^2 tiles, ms per call by batch size: dense leaves / stacked-triangle tree nodes, with T and R only
 GEQRT_MS = {True: {1: 18.4, 2: 21.5, 4: 27.1, 8: 36.4, 16: 60.0, 32: 105.0}, False: {1: 16.5, 2: 19.5, 4: 24.0, 8: 31.0, 16: 47.2, 32: 77.8}}
