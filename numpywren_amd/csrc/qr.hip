@@ -51,6 +51,8 @@ inline int64_t superblock_width_max() {
 }
 constexpr int LA = 2 * OB;  // columns right of a superblock that its blocks' own (k = OB) updates keep current: the panel
                             // chain's two-block window must never reach into columns that still miss earlier reflectors
+                            // (OB is NOT enough: the next superblock's first block already updates its successor per panel
+                            //  -- measured: wrong factors at LA = OB; LA = 3 OB: the same speed)
 __device__ inline double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
