@@ -168,10 +168,14 @@ __device__ inline void block_to_tile_tri(int tiles, bool spread, int& tm, int& t
 // TAG only gives the kernel a distinct symbol: TAG 1 = the tile-level trailing update issued by
 // npw_dgemm_nt_sub (kernels.syrk), so profilers report it separately from the many smaller GEMMs that
 // trsm / potrf / geqrt run through the same tiling; TAG 2 = its symmetric form (X == Y, lower tiles only).
-template <typename T, int BM, int BN, int BK, bool A_KC, bool B_KC, bool EDGE, int TAG = 0>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) {
-    constexpr int NT = 256;              // threads per workgroup: 4 waves as 2 x 2
-    constexpr int WAVES_N = 2;
+// NW = waves along n: 2 (4 waves as 2 x 2, two workgroups per CU) or 4 (8 waves as 2 x 4, ONE workgroup per CU holding a
+// 128 x 256 tile: the same waves per CU, but an A panel is fetched once for 256 output columns -- for products whose n is
+// exactly two 128-wide tile columns, where the two workgroups that share an A panel drift apart in their k loops and both
+// fetch it from memory: QR's far V^T W product read its operands 2.1 x, profiles/r04_qr32r_hbm_bytes.txt).
+template <typename T, int BM, int BN, int BK, bool A_KC, bool B_KC, bool EDGE, int TAG = 0, int NW = 2>
+__global__ __launch_bounds__(128 * NW, 2) void gemm_kernel(const GemmParams<T> p_in) {
+    constexpr int NT = 128 * NW;         // threads per workgroup
+    constexpr int WAVES_N = NW;
     GemmParams<T> p = p_in;
     if (gridDim.z > 1 && p.use_delta) {
         // (indexed in the kernel-argument segment itself: a dynamically indexed array inside the local copy `p` would
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams<T> p_in) 
     }
 }
 
-template <typename T, int BM, int BN, int BK, bool A_KC, bool B_KC, bool EDGE>
+template <typename T, int BM, int BN, int BK, bool A_KC, bool B_KC, bool EDGE, int NW = 2>
 int launch(const GemmParams<T>& p, hipStream_t stream) {
     using TR = MfmaTraits<T>;
     constexpr int LDKC = BK + TR::PADK;
@@ -580,24 +584,24 @@ int launch(const GemmParams<T>& p, hipStream_t stream) {
             return NPW_OK;
         }
     }
-    auto kern = gemm_kernel<T, BM, BN, BK, A_KC, B_KC, EDGE, 0>;
+    auto kern = gemm_kernel<T, BM, BN, BK, A_KC, B_KC, EDGE, 0, NW>;
     static thread_local bool attr_set = false;
     if (!attr_set && smem > 48 * 1024) {
         NPW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(nwg, nsplit, nbatch), dim3(256), smem, stream, p);
+    hipLaunchKernelGGL(kern, dim3(nwg, nsplit, nbatch), dim3(128 * NW), smem, stream, p);
     NPW_LAUNCH_CHECK();
     return NPW_OK;
 }
 
-template <typename T, int BM, int BN, int BK, bool EDGE>
+template <typename T, int BM, int BN, int BK, bool EDGE, int NW = 2>
 int dispatch_layout(bool a_kc, bool b_kc, const GemmParams<T>& p, hipStream_t s) {
-    if (a_kc && b_kc) return launch<T, BM, BN, BK, true, true, EDGE>(p, s);
-    if (a_kc && !b_kc) return launch<T, BM, BN, BK, true, false, EDGE>(p, s);
-    if (!a_kc && b_kc) return launch<T, BM, BN, BK, false, true, EDGE>(p, s);
-    return launch<T, BM, BN, BK, false, false, EDGE>(p, s);
+    if (a_kc && b_kc) return launch<T, BM, BN, BK, true, true, EDGE, NW>(p, s);
+    if (a_kc && !b_kc) return launch<T, BM, BN, BK, true, false, EDGE, NW>(p, s);
+    if (!a_kc && b_kc) return launch<T, BM, BN, BK, false, true, EDGE, NW>(p, s);
+    return launch<T, BM, BN, BK, false, false, EDGE, NW>(p, s);
 }
 
 // D = alpha * sum_s P[s] + beta * C over the split-K partial products P[s] (each m x n, contiguous)
@@ -777,6 +781,14 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
         return e ? (int64_t)atoi(e) : (int64_t)512;  // k <= 256: prologue/epilogue-bound, more workgroups win
     }();
     const bool big = !opts.force_small && (opts.force_big || (wg128 >= (k <= 256 ? big_min_shortk : big_min)));
+    if constexpr (sizeof(T) == 8) {
+        if (opts.wide_n && big && vec_ok && k_ok && (m % 128 == 0) && (n % 256 == 0) && !p.lower_only && opts.tag == 0 && ta && !tb && opts.k_chunk_ == 0) {
+            // op(A) = T, op(B) = N with n a multiple of 256: one 8-wave workgroup per 128 x 256 tile (see gemm_kernel)
+            p.tiles_m = (int)(m / 128);
+            p.tiles_n = (int)(n / 256);
+            return launch<T, 128, 256, BK, false, false, false, 4>(p, stream);
+        }
+    }
     if (big) {
         p.tiles_m = (int)ceil_div(m, 128);
         p.tiles_n = (int)ceil_div(n, 128);

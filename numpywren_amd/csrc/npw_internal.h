@@ -53,6 +53,8 @@ struct GemmOpts {
                               // form (op(A) op(B) = X X^T, strict_lower): every tile also writes its mirror tile
     bool force_big = false;   // take the 128 x 128 tiling whatever the grid size
     bool force_small = false; // take the 64 x 64 tiling whatever the grid size (finer k limits for triangular operands)
+    bool wide_n = false;      // op(A) = T, op(B) = N, fp64, n % 256 == 0: 128 x 256 tiles on 8-wave workgroups (an A panel is fetched
+                              // once for 256 output columns instead of by two workgroups that drift apart)
     int splitk = 1;           // > 1 with splitk_ws: cut k into this many chunks (skinny outputs, long k)
     void* splitk_ws = nullptr;  // splitk * m * n elements of scratch
     int* splitk_keep = nullptr;  // non-NULL: leave the partial products in splitk_ws ([problem][split][m][n], alpha and

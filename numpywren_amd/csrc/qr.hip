@@ -792,6 +792,10 @@ inline bool near_fast(int64_t rows, int64_t pb, int64_t nc, int rs, const double
     (void)rs;
     return pb == PB && nc % 16 == 0 && rows % 16 == 0 && ldv % 2 == 0 && (reinterpret_cast<uintptr_t>(Vp) & 15) == 0;
 }
+static const bool far_wide_tiles = [] {
+    const char* e = getenv("NPW_QR_FAR_WIDE");
+    return e == nullptr || atoi(e) != 0;
+}();
 static const bool far_nt_form = [] {
     const char* e = getenv("NPW_QR_FAR_NT");
     return e == nullptr || atoi(e) != 0;
@@ -877,6 +881,7 @@ int apply_panel(const Batch& b, const double* Wp, int64_t ldv, int64_t mp, int64
     } else if (pb >= 256 && far_nt_form) {
         // superblock reflector: the temporaries are kept TRANSPOSED (X^T = W2^T V, nc x pb), so that the rank-pb update reads
         // both operands along k -- the N / T form, the only one with the pinned load / store interleave of gemm.hip
+        g1.wide_n = far_wide_tiles;
         rc = gemm<double>('T', 'N', nc, pb, mp, 1.0, W2, ldv, Wp, ldv, 0.0, nullptr, 0, X1, pb, g1, s);
         if (rc) return rc;
         GemmOpts g2 = batched(b, sX1, b.sT, 0, sX2);
