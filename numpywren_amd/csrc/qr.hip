@@ -233,6 +233,7 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
     bool live[RPT];
     int64_t wrow[RPT];
     double pk[RPT][PB], acc[PB];
+    const bool vec = pb == PB && (ldw & 1) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;   // (uniform)
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
         r[i] = (blockIdx.x * RPT + i) * SLAB + tid;
@@ -240,8 +241,23 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
         // The panel's rows may be two segments of the matrix (two stacked triangles: the pb pivot rows, then the leading
         // rows of the lower block): row r of the panel is row r (r < split) or r + gap of W.
         wrow[i] = (int64_t)r[i] + (r[i] >= split ? gap : 0);
+        if (vec) {   // a full panel with 16-byte aligned rows: 16 loads of 16 bytes per row instead of 32 of 8
+            if (live[i]) {
+                const double2* src = reinterpret_cast<const double2*>(W + wrow[i] * ldw);
 #pragma unroll
-        for (int k = 0; k < PB; ++k) pk[i][k] = (live[i] && k < pb) ? W[wrow[i] * ldw + k] : 0.0;
+                for (int k = 0; k < PB; k += 2) {
+                    const double2 v = src[k >> 1];
+                    pk[i][k] = v.x;
+                    pk[i][k + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < PB; ++k) pk[i][k] = 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PB; ++k) pk[i][k] = (live[i] && k < pb) ? W[wrow[i] * ldw + k] : 0.0;
+        }
     }
     if (blockIdx.x == 0)
         for (int i = tid; i < PB * TLD; i += SLAB) Tl[i] = 0.0;
@@ -415,10 +431,20 @@ __global__ __launch_bounds__(SLAB) void qr_panel3_kernel(int mp, int pb, double*
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
         if (live[i]) {
+            if (vec) {
+                double2* dst = reinterpret_cast<double2*>(W + wrow[i] * ldw);
+#pragma unroll
+                for (int k = 0; k < PB; k += 2) {
+                    double2 v;
+                    v.x = (r[i] > k) ? pk[i][k] : (r[i] == k ? 1.0 : 0.0);
+                    v.y = (r[i] > k + 1) ? pk[i][k + 1] : (r[i] == k + 1 ? 1.0 : 0.0);
+                    dst[k >> 1] = v;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < PB; ++k) {
                 if (k < pb) {
-                    W[wrow[i] * ldw + k] = (r[i] > k) ? pk[i][k] : (r[i] == k ? 1.0 : 0.0);
+                    if (!vec) W[wrow[i] * ldw + k] = (r[i] > k) ? pk[i][k] : (r[i] == k ? 1.0 : 0.0);
                     if (i == 0 && r[0] < pb) Rjj[(int64_t)r[0] * ldr + k] = (r[0] <= k) ? pk[0][k] : 0.0;
                 }
             }
@@ -449,9 +475,9 @@ struct QrWorkspace {
     double* Gb;   // OB x OB     V_b^T V_b of the current outer block
     double* Part;    // 2 x slabs x PB hand-off slots (16 bytes each) of the panel kernel
     double* RowBuf;  // 2 x PB slots: the next pivot row
-    double* XnA;     // PB x 2 OB   near update temporaries
-    double* XnB;     // PB x 2 OB
-    double* XnS;     // 32 x PB x 2 OB  split-K partials of the near updates
+    double* XnA;     // PB x 4 OB   near update temporaries (2 OB columns; as 16-byte slots in the one-launch form)
+    double* XnB;     // PB x 4 OB
+    double* XnS;     // 64 x PB x 2 OB  split-K / per-slab partials of the near updates
     double* YnA;     // the same three for the next block's near updates, which run beside the own block's on another stream
     double* YnB;
     double* YnS;
@@ -473,8 +499,8 @@ QrWorkspace carve(void* ws, int64_t m, int64_t n, int count, int batch) {
     q.sGb = (int64_t)OB * OB;
     q.sPart = (int64_t)align2((size_t)4 * ceil_div(m, SLAB) * PB);
     q.sRow = 4 * PB;
-    q.sXn = (int64_t)PB * 2 * OB;
-    q.sXnS = (int64_t)32 * PB * 2 * OB;
+    q.sXn = (int64_t)PB * 4 * OB;          // (near_fused_kernel keeps X2 as 16-byte slots: twice the doubles)
+    q.sXnS = (int64_t)64 * PB * 2 * OB;    // (... and up to 32 slabs' partials of 2 OB columns as slots)
     q.sF = (int64_t)align2((size_t)superblock_width_max() * n);   // (small batches: SB = n, no far update, unused)
     q.sGf = 4 * q.sF;
     q.sTs = batch >= 8 ? q.sF : (int64_t)align2((size_t)ceil_div(n, OB) * OB * n);   // ld = SB (= n rounded up for small batches)
@@ -628,19 +654,16 @@ __global__ void move_block_rows_kernel(int ob, int pbw, int64_t c_end, double* W
 typedef double nd4_t __attribute__((ext_vector_type(4)));
 constexpr int NEAR_NT = 4;             // 16-column MFMA tiles per workgroup (one 64-column chunk)
 
-template <bool EDGE>
-__global__ __launch_bounds__(256) void near_vtw_kernel(int rows, int pb, int nc, const double* V, int64_t ldv, int64_t sV,
-                                                        const double* W, int64_t ldw, int64_t sW, double* P, int rs) {
-    __shared__ double red[2][2 * NEAR_NT * 4 * 64];   // two waves' accumulators (32 KB)
-    const int z = blockIdx.z, slab = blockIdx.x, nslab = gridDim.x;
-    const int c0 = blockIdx.y * 16 * NEAR_NT;
-    V += (int64_t)z * sV;
-    W += (int64_t)z * sW;
-    P += ((int64_t)z * nslab + slab) * pb * nc;
+// The slab's partial product V[rows of this wave]^T W2[same rows] for one 64-column chunk, summed over the four waves of
+// the workgroup (fixed order: (w0 + w2) + (w1 + w3)); the result is left in wave 0's `acc` (rows 16 i + lg + 4 r of the
+// pb x 64 block, column 16 j + li).  red: 2 x 2048 doubles of LDS.
+// KEEP: the slab is one round of 16 rows per wave (rw == 16) and `keep` receives the wave's W2 values, which are then already
+// in the layout of the update's C operand (keep[r][j] = W2[r_begin + lg + 4 r][c0 + 16 j + li]).
+template <bool EDGE, bool KEEP = false>
+__device__ __forceinline__ void near_vtw_body(int rows, int pb, int nc, int c0, int r_begin, int rw, const double* V, int64_t ldv,
+                                              const double* W, int64_t ldw, double* red, nd4_t (&acc)[2][NEAR_NT],
+                                              double (*keep)[NEAR_NT] = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-    const int rw = rs >> 2;                      // rows per wave (a multiple of 16)
-    const int r_begin = slab * rs + wave * rw;
-    nd4_t acc[2][NEAR_NT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -675,6 +698,7 @@ __global__ __launch_bounds__(256) void near_vtw_kernel(int rows, int pb, int nc,
             for (int j = 0; j < NEAR_NT; ++j) {
                 acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], bb[u][j], acc[0][j], 0, 0, 0);
                 acc[1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], bb[u][j], acc[1][j], 0, 0, 0);
+                if constexpr (KEEP) keep[u][j] = bb[u][j];
             }
         vrow += 16 * ldv;
         wrow += 16 * ldw;
@@ -686,7 +710,7 @@ __global__ __launch_bounds__(256) void near_vtw_kernel(int rows, int pb, int nc,
 #pragma unroll
             for (int j = 0; j < NEAR_NT; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[slot][((i * NEAR_NT + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+                for (int r = 0; r < 4; ++r) red[slot * 2048 + ((i * NEAR_NT + j) * 4 + r) * 64 + lane] = acc[i][j][r];
     };
     auto add = [&](int slot) {
 #pragma unroll
@@ -694,7 +718,7 @@ __global__ __launch_bounds__(256) void near_vtw_kernel(int rows, int pb, int nc,
 #pragma unroll
             for (int j = 0; j < NEAR_NT; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] += red[slot][((i * NEAR_NT + j) * 4 + r) * 64 + lane];
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += red[slot * 2048 + ((i * NEAR_NT + j) * 4 + r) * 64 + lane];
     };
     if (wave >= 2) put(wave - 2);
     __syncthreads();
@@ -702,42 +726,16 @@ __global__ __launch_bounds__(256) void near_vtw_kernel(int rows, int pb, int nc,
     __syncthreads();
     if (wave == 1) put(0);
     __syncthreads();
-    if (wave == 0) {
-        add(0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < NEAR_NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int mm = 16 * i + lg + 4 * r, col = c0 + 16 * j + li;
-                    if (mm < pb && col < nc) P[(int64_t)mm * nc + col] = acc[i][j][r];
-                }
-    }
+    if (wave == 0) add(0);
 }
 
+// W2[rows of this wave] -= V[same rows] X2 for one 64-column chunk; bf = X2 in the B-operand layout: lane group g takes
+// k = 8 g .. 8 g + 7 at the eight MFMA steps (any bijection does as long as both operands agree), so that a lane's eight
+// values of V are 64 contiguous bytes of one row.
 template <bool EDGE>
-__global__ __launch_bounds__(256) void near_update_kernel(int rows, int pb, int nc, const double* V, int64_t ldv, int64_t sV,
-                                                           const double* X2, int64_t ldx, int64_t sX, double* W, int64_t ldw,
-                                                           int64_t sW, int rs) {
-    const int z = blockIdx.z, slab = blockIdx.x;
-    const int c0 = blockIdx.y * 16 * NEAR_NT;
-    V += (int64_t)z * sV;
-    W += (int64_t)z * sW;
-    X2 += (int64_t)z * sX;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-    const int rw = rs >> 2;                      // rows per wave (a multiple of 16)
-    const int r_begin = slab * rs + wave * rw;
-    // lane group g takes k = 8 g .. 8 g + 7 at the eight MFMA steps (any bijection does as long as both operands agree):
-    // a lane's eight values of V are then 64 contiguous bytes of one row
-    double bf[8][NEAR_NT];
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-#pragma unroll
-        for (int j = 0; j < NEAR_NT; ++j) {
-            const int k = 8 * lg + s, col = c0 + 16 * j + li;
-            bf[s][j] = (k < pb && col < nc) ? X2[(int64_t)k * ldx + col] : 0.0;
-        }
+__device__ __forceinline__ void near_update_body(int rows, int pb, int nc, int c0, int r_begin, int rw, const double* V, int64_t ldv,
+                                                 const double (&bf)[8][NEAR_NT], double* W, int64_t ldw) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
     for (int t = 0; t < rw; t += 16) {
         if (!EDGE && r_begin + t >= rows) break;  // (wave-uniform) whole groups of 16 rows
         const int ra = r_begin + t + li;          // the row this lane feeds into the A operand
@@ -779,6 +777,213 @@ __global__ __launch_bounds__(256) void near_update_kernel(int rows, int pb, int 
     }
 }
 
+template <bool EDGE>
+__global__ __launch_bounds__(256) void near_vtw_kernel(int rows, int pb, int nc, const double* V, int64_t ldv, int64_t sV,
+                                                        const double* W, int64_t ldw, int64_t sW, double* P, int rs) {
+    __shared__ double red[2 * 2048];   // two waves' accumulators (32 KB)
+    const int z = blockIdx.z, slab = blockIdx.x, nslab = gridDim.x;
+    const int c0 = blockIdx.y * 16 * NEAR_NT;
+    V += (int64_t)z * sV;
+    W += (int64_t)z * sW;
+    P += ((int64_t)z * nslab + slab) * pb * nc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int rw = rs >> 2;                      // rows per wave (a multiple of 16)
+    nd4_t acc[2][NEAR_NT];
+    near_vtw_body<EDGE>(rows, pb, nc, c0, slab * rs + wave * rw, rw, V, ldv, W, ldw, red, acc);
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NEAR_NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mm = 16 * i + lg + 4 * r, col = c0 + 16 * j + li;
+                    if (mm < pb && col < nc) P[(int64_t)mm * nc + col] = acc[i][j][r];
+                }
+    }
+}
+
+template <bool EDGE>
+__global__ __launch_bounds__(256) void near_update_kernel(int rows, int pb, int nc, const double* V, int64_t ldv, int64_t sV,
+                                                           const double* X2, int64_t ldx, int64_t sX, double* W, int64_t ldw,
+                                                           int64_t sW, int rs) {
+    const int z = blockIdx.z, slab = blockIdx.x;
+    const int c0 = blockIdx.y * 16 * NEAR_NT;
+    V += (int64_t)z * sV;
+    W += (int64_t)z * sW;
+    X2 += (int64_t)z * sX;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int rw = rs >> 2;                      // rows per wave (a multiple of 16)
+    double bf[8][NEAR_NT];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int j = 0; j < NEAR_NT; ++j) {
+            const int k = 8 * lg + s, col = c0 + 16 * j + li;
+            bf[s][j] = (k < pb && col < nc) ? X2[(int64_t)k * ldx + col] : 0.0;
+        }
+    near_update_body<EDGE>(rows, pb, nc, c0, slab * rs + wave * rw, rw, V, ldv, bf, W, ldw);
+}
+
+// The three steps in ONE launch for a latency-bound (single or small-batch) factorisation, where the chain waits for
+// each of them: per-slab partial products -> hand-off -> reduce / T^T -> hand-off -> update.  Every workgroup of the
+// launch waits for the others (tagged slots, bounded spins, as in the panel kernel): the whole grid has to be resident,
+// so the host only takes this form when the grid is at most one workgroup per compute unit of the stream.
+//   part: [z][chunk][slab][32 x 64] slots -- the slabs' partial products of the chunk
+//   xs  : [z][chunk][32 x 64] slots       -- X2 = T^T (sum of the partials [+ Wtop])
+// The 64 columns of a chunk are dealt out to the slabs' workgroups for the reduction (cpw columns each).  Wtop != NULL:
+// the stacked-triangle form (the reflectors' top part is the identity): X1 also takes the pb top rows of the columns, and
+// the workgroup that reduces a column leaves its final R entries Wtop - X2 in Rdst and clears Wtop.
+template <bool EDGE>
+__global__ __launch_bounds__(256) void near_fused_kernel(int rows, int pb, int nc, const double* V, int64_t ldv, int64_t sV, double* W,
+                                                          int64_t ldw, int64_t sW, double* Wtop, double* Rdst, int64_t ldr,
+                                                          int64_t sR, const double* Tjj, int64_t ldt, int64_t sT, slot_t* part,
+                                                          slot_t* xs, unsigned long long tag, int rs) {
+    constexpr int CH = 16 * NEAR_NT;                 // columns of a chunk
+    __shared__ double lds[32 * 33 + 2 * 32 * (CH + 1)];   // phase 1: two waves' accumulators (2 x 2048); then T, X1, X2
+    static_assert(32 * 33 + 2 * 32 * (CH + 1) >= 2 * 2048, "the accumulators of phase 1 need 2 x 2048 doubles");
+    double* const Ts = lds;                          // [32][33]
+    double* const X1s = lds + 32 * 33;               // [32][CH + 1]
+    double* const X2s = X1s + 32 * (CH + 1);         // [32][CH + 1]
+    const int z = blockIdx.z, slab = blockIdx.x, nslab = gridDim.x, chunk = blockIdx.y, nchunk = gridDim.y;
+    const int c0 = chunk * CH;
+    V += (int64_t)z * sV;
+    W += (int64_t)z * sW;
+    Tjj += (int64_t)z * sT;
+    if (Wtop) {
+        Wtop += (int64_t)z * sW;
+        Rdst += (int64_t)z * sR;
+    }
+    part += ((size_t)z * nchunk + chunk) * nslab * (32 * CH);
+    xs += ((size_t)z * nchunk + chunk) * (32 * CH);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int rw = rs >> 2;
+    const int r_begin = slab * rs + wave * rw;
+    const bool one = rw == 16;                       // (uniform) one round per wave: W2 and V stay in registers for the update
+    // this workgroup's columns of the chunk (the reduction's work is dealt out to the slabs)
+    const int cpw = (CH + nslab - 1) / nslab;
+    const int cb = slab * cpw, ce = (cb + cpw < CH) ? cb + cpw : CH;   // [cb, ce): empty for the last slabs when nslab > CH / cpw
+    // T (needed after the first hand-off) is fetched now, behind the loads of phase 1
+    double tpre[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int i = tid + 256 * h, a = i >> 5, bcol = i & 31;
+        tpre[h] = (cb < ce && a < pb && bcol < pb) ? Tjj[(int64_t)a * ldt + bcol] : 0.0;
+    }
+    double keep[4][NEAR_NT], af[8];
+    {
+        nd4_t acc[2][NEAR_NT];
+        if (one)
+            near_vtw_body<EDGE, true>(rows, pb, nc, c0, r_begin, rw, V, ldv, W, ldw, lds, acc, keep);
+        else
+            near_vtw_body<EDGE>(rows, pb, nc, c0, r_begin, rw, V, ldv, W, ldw, lds, acc);
+        if (wave == 0) {
+            slot_t* mine = part + (size_t)slab * (32 * CH);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NEAR_NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st_slot(mine + (16 * i + lg + 4 * r) * CH + 16 * j + li, acc[i][j][r], tag);
+        }
+    }
+    if (one) {
+        // the update's A operand (lane group g: k = 8 g .. 8 g + 7 of row r_begin + li), requested before the waits
+        const int ra = r_begin + li;
+        if constexpr (!EDGE) {
+            if (r_begin < rows) {
+                const double2* src = reinterpret_cast<const double2*>(V + (int64_t)ra * ldv + 8 * lg);
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const double2 v = src[h];
+                    af[2 * h] = v.x;
+                    af[2 * h + 1] = v.y;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) af[s] = (ra < rows && 8 * lg + s < pb) ? V[(int64_t)ra * ldv + 8 * lg + s] : 0.0;
+        }
+    }
+    __syncthreads();   // (the accumulators in LDS are dead: T, X1, X2 take their place)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int i = tid + 256 * h;
+        Ts[(i >> 5) * 33 + (i & 31)] = tpre[h];
+    }
+    // ---- this workgroup's columns: sum of the slabs' partials (fixed order) [+ Wtop], T^T, publish ----
+    {
+        const int l = tid >> 3, sub = tid & 7;   // row of X1, 8 lanes per row
+        for (int c = cb + sub; c < ce; c += 8) {
+            const slot_t* base = part + l * CH + c;
+            double a = 0.0;
+            for (int g = 0; g < nslab; g += 4) {
+                double u0, u1, u2, u3;
+                const bool n1 = g + 1 < nslab, n2 = g + 2 < nslab, n3 = g + 3 < nslab;
+                ld_slots4<4>(base + (size_t)g * (32 * CH), base + (size_t)(n1 ? g + 1 : g) * (32 * CH),
+                             base + (size_t)(n2 ? g + 2 : g) * (32 * CH), base + (size_t)(n3 ? g + 3 : g) * (32 * CH), true, n1, n2, n3,
+                             tag, 1, u0, u1, u2, u3);
+                a += u0;
+                if (n1) a += u1;
+                if (n2) a += u2;
+                if (n3) a += u3;
+            }
+            if (Wtop && l < pb && c0 + c < nc) a += Wtop[(int64_t)l * ldw + c0 + c];
+            X1s[l * (CH + 1) + c] = a;
+        }
+    }
+    __syncthreads();
+    {
+        const int l = tid >> 3, sub = tid & 7;
+        for (int c = cb + sub; c < ce; c += 8) {
+            double x = 0.0;
+            for (int i = 0; i <= l; ++i) x = fma(Ts[i * 33 + l], X1s[i * (CH + 1) + c], x);
+            st_slot(xs + l * CH + c, x, tag);
+            if (Wtop && l < pb && c0 + c < nc) {
+                double* wt = Wtop + (int64_t)l * ldw + c0 + c;
+                Rdst[(int64_t)l * ldr + c0 + c] = *wt - x;
+                *wt = 0.0;
+            }
+        }
+    }
+    // ---- all of X2 for the chunk ----
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int e0 = tid + 1024 * h;
+        double u0, u1, u2, u3;
+        ld_slots4<4>(xs + e0, xs + e0 + 256, xs + e0 + 512, xs + e0 + 768, true, true, true, true, tag, 1, u0, u1, u2, u3);
+        X2s[(e0 >> 6) * (CH + 1) + (e0 & 63)] = u0;
+        X2s[((e0 + 256) >> 6) * (CH + 1) + (e0 & 63)] = u1;
+        X2s[((e0 + 512) >> 6) * (CH + 1) + (e0 & 63)] = u2;
+        X2s[((e0 + 768) >> 6) * (CH + 1) + (e0 & 63)] = u3;
+    }
+    __syncthreads();
+    double bf[8][NEAR_NT];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int j = 0; j < NEAR_NT; ++j) bf[s][j] = X2s[(8 * lg + s) * (CH + 1) + 16 * j + li];   // (zero beyond pb / nc: T and the partials are)
+    if (!one) {
+        near_update_body<EDGE>(rows, pb, nc, c0, r_begin, rw, V, ldv, bf, W, ldw);
+        return;
+    }
+    if (!EDGE && r_begin >= rows) return;   // (wave-uniform)
+    nd4_t acc[NEAR_NT];
+#pragma unroll
+    for (int j = 0; j < NEAR_NT; ++j) acc[j] = nd4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int j = 0; j < NEAR_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], bf[s][j], acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NEAR_NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = r_begin + lg + 4 * r, col = c0 + 16 * j + li;
+            if (EDGE ? (row < rows && col < nc) : (16 * j < nc - c0)) W[(int64_t)row * ldw + col] = keep[r][j] - acc[j][r];
+        }
+}
+
 // rows per workgroup of the two kernels above: 256 when that already gives the chip a few hundred workgroups, else 64;
 // never more slabs than the partial-product scratch holds
 inline int near_slab_rows(const Batch& b, int64_t rows, int64_t pb, int64_t nc, size_t skcap) {
@@ -810,6 +1015,29 @@ static const bool near_kernels_on = [] {
     const char* e = getenv("NPW_QR_NEAR_KERNELS");
     return e == nullptr || atoi(e) != 0;
 }();
+static const bool near_fused_on = [] {
+    const char* e = getenv("NPW_QR_NEAR_FUSED");
+    return e == nullptr || atoi(e) != 0;
+}();
+// Rows per slab for near_fused_kernel, or 0 when the three-launch form has to run: the one launch is for latency-bound
+// factorisations (fewer than 8 matrices), its whole grid has to be resident (at most one workgroup per compute unit of the
+// stream), a chunk's 64 columns are dealt out to at most 64 slabs, and the slots have to fit the scratch (skcap doubles
+// per matrix for the partials, sX2 for X2; a slot is two doubles).
+inline int fused_slab_rows(const Batch& b, int64_t rows, int64_t nc, size_t skcap, int64_t sX2, unsigned long long tag, hipStream_t s) {
+    if (!near_fused_on || tag == 0 || b.count >= 8) return 0;
+    const int64_t chunks = ceil_div(nc, 16 * NEAR_NT);
+    if (chunks * 2 * 32 * 16 * NEAR_NT > sX2) return 0;
+    const int64_t cus = stream_cu_count(s);
+    static const int rs_min = [] {
+        const char* e = getenv("NPW_QR_FUSED_RS");
+        return e ? atoi(e) : 64;
+    }();
+    for (int rs = rs_min; rs <= 1024; rs *= 2) {
+        const int64_t nslab = ceil_div(rows, rs);
+        if (nslab <= 16 * NEAR_NT && nslab * chunks * 2 * 32 * 16 * NEAR_NT <= (int64_t)skcap && nslab * chunks * b.count <= cus) return rs;
+    }
+    return 0;
+}
 
 // Split-K factor for X1 = V^T W2 (pb x nc, contraction over `rows`): enough workgroups for the chip.  Panel- and
 // block-wide reflectors run on 64 x 64 tiles (one tile row counted, as tuned in rounds 2 - 3), superblock-wide ones on
@@ -832,7 +1060,8 @@ inline bool whole_chip_of_big_tiles(const Batch& b, int64_t m, int64_t n) {
 // skcap elements per matrix, the matrices' regions back to back.
 int apply_panel(const Batch& b, const double* Wp, int64_t ldv, int64_t mp, int64_t pb, const double* Tjj, int64_t ldt,
                 double* W2, int64_t nc, double* X1, int64_t sX1, double* X2, int64_t sX2, double* skws, size_t skcap,
-                double* Rdst, int64_t ldr, hipStream_t s) {  // Rdst == nullptr: the caller moves the R rows later
+                double* Rdst, int64_t ldr, hipStream_t s, unsigned long long tag = 0) {  // Rdst == nullptr: the caller moves the R rows later
+    // tag != 0: a sequence tag for the hand-off slots of near_fused_kernel, unique to this call of this factorisation
     // X1 = V_p^T W2 is pb x nc with a contraction over all mp rows: split k so that the launch has a few hundred
     // workgroups instead of nc/64
     GemmOpts g1 = batched(b, b.sV, b.sV, 0, sX1);
@@ -847,7 +1076,21 @@ int apply_panel(const Batch& b, const double* Wp, int64_t ldv, int64_t mp, int64
     bool updated = false;
     if (near_kernels_on && pb <= PB && skws != nullptr && (size_t)pb * nc <= skcap) {
         // panel-wide reflector: the streaming kernels (per-slab partial products, one small kernel that reduces them in a
-        // fixed order and applies T^T, the rank-pb update)
+        // fixed order and applies T^T, the rank-pb update) -- as one launch where the chain waits for them
+        if (const int frs = fused_slab_rows(b, mp, nc, skcap, sX2, tag, s)) {
+            const dim3 grid((unsigned)ceil_div(mp, frs), (unsigned)ceil_div(nc, 16 * NEAR_NT), (unsigned)b.count);
+            const bool fast = near_fast(mp, pb, nc, frs, Wp, ldv);
+            hipLaunchKernelGGL(fast ? near_fused_kernel<false> : near_fused_kernel<true>, grid, dim3(256), 0, s, (int)mp, (int)pb, (int)nc,
+                               Wp, ldv, b.sV, W2, ldv, b.sV, (double*)nullptr, (double*)nullptr, (int64_t)0, (int64_t)0, Tjj, ldt, b.sT,
+                               reinterpret_cast<slot_t*>(skws), reinterpret_cast<slot_t*>(X2), tag, frs);
+            NPW_LAUNCH_CHECK();
+            if (Rdst == nullptr) return NPW_OK;
+            const unsigned gy = (unsigned)(pb < 32 ? pb : 32);
+            hipLaunchKernelGGL(move_rows_kernel, dim3((unsigned)ceil_div(nc, 256), gy, (unsigned)b.count), dim3(256), 0, s, (int)pb, nc,
+                               W2, ldv, b.sV, Rdst, ldr, b.sR);
+            NPW_LAUNCH_CHECK();
+            return NPW_OK;
+        }
         const int rs = near_slab_rows(b, mp, pb, nc, skcap);
         const dim3 grid((unsigned)ceil_div(mp, rs), (unsigned)ceil_div(nc, 16 * NEAR_NT), (unsigned)b.count);
         const bool fast = near_fast(mp, pb, nc, rs, Wp, ldv);
@@ -936,7 +1179,7 @@ __global__ void move_rows_sub_kernel(int rows, int64_t cols, double* W, int64_t 
 //   X1 = Wtop + Vbot^T Wbot,   X2 = T_p^T X1,   Wbot -= Vbot X2,   R rows = Wtop - X2 (Wtop cleared).
 int apply_tri(const Batch& b, const double* Vbot, int64_t ldv, int64_t rows, int64_t pb, const double* Tjj, int64_t ldt,
               double* Wtop, double* Wbot, int64_t nc, double* X1, int64_t sX1, double* X2, int64_t sX2, double* skws,
-              size_t skcap, double* Rdst, int64_t ldr, hipStream_t s) {
+              size_t skcap, double* Rdst, int64_t ldr, hipStream_t s, unsigned long long tag = 0) {
     GemmOpts g1 = batched(b, b.sV, b.sV, b.sV, sX1);
     int64_t want = wanted_splits(b, pb, nc, rows);
     if (skws != nullptr && want > 1 && (size_t)want * pb * nc <= skcap) {
@@ -948,6 +1191,15 @@ int apply_tri(const Batch& b, const double* Vbot, int64_t ldv, int64_t rows, int
     int rc;
     bool updated = false;   // Wbot -= Vbot X2 already done (the streaming kernels)
     if (near_kernels_on && pb <= PB && skws != nullptr && (size_t)pb * nc <= skcap) {
+        if (const int frs = fused_slab_rows(b, rows, nc, skcap, sX2, tag, s)) {   // one launch, the R rows included
+            const dim3 grid((unsigned)ceil_div(rows, frs), (unsigned)ceil_div(nc, 16 * NEAR_NT), (unsigned)b.count);
+            const bool fast = near_fast(rows, pb, nc, frs, Vbot, ldv);
+            hipLaunchKernelGGL(fast ? near_fused_kernel<false> : near_fused_kernel<true>, grid, dim3(256), 0, s, (int)rows, (int)pb,
+                               (int)nc, Vbot, ldv, b.sV, Wbot, ldv, b.sV, Wtop, Rdst, ldr, b.sR, Tjj, ldt, b.sT,
+                               reinterpret_cast<slot_t*>(skws), reinterpret_cast<slot_t*>(X2), tag, frs);
+            NPW_LAUNCH_CHECK();
+            return NPW_OK;
+        }
         updated = true;
         const int rs = near_slab_rows(b, rows, pb, nc, skcap);
         const dim3 grid((unsigned)ceil_div(rows, rs), (unsigned)ceil_div(nc, 16 * NEAR_NT), (unsigned)b.count);
@@ -1237,10 +1489,12 @@ int geqrt_core(const Batch& b_in, int64_t m, int64_t n, bool tri, double* V, int
             const int64_t nc = chain_end - j0 - pb;
             if (nc > 0) {
                 if (!split_near && j0 == b0 && b0 > 0 && near_end > own_end) NPW_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
+                // (the panel kernel's columns use the tags 0 .. PB - 1 of the panel's 64; the fused near update takes the next one)
+                const unsigned long long near_tag = call_tag + (unsigned long long)(j0 / PB) * 64 + PB;
                 int rc = tri ? apply_tri(b, Vlow + j0, ldv, j0 + pb, pb, Tq + j0 * ldtb + j0, ldtb, Wp + pb, Vlow + j0 + pb, nc, q.XnA,
-                                         q.sXn, q.XnB, q.sXn, q.XnS, (size_t)q.sXnS, R + j0 * ldr + j0 + pb, ldr, s)
+                                         q.sXn, q.XnB, q.sXn, q.XnS, (size_t)q.sXnS, R + j0 * ldr + j0 + pb, ldr, s, near_tag)
                              : apply_panel(b, Wp, ldv, mp, pb, Tq + j0 * ldtb + j0, ldtb, Wp + pb, nc, q.XnA, q.sXn, q.XnB, q.sXn,
-                                           q.XnS, (size_t)q.sXnS, nullptr, ldr, s);   // R rows: moved per block, below
+                                           q.XnS, (size_t)q.sXnS, nullptr, ldr, s, near_tag);   // R rows: moved per block, below
                 if (rc) return rc;
             }
         }

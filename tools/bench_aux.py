@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=1, help="HIP streams of the executor (pipeline_width)")
+    ap.add_argument("--task-times", action="store_true", help="bdfac / qr: one extra run with per-kernel device times")
     ap.add_argument("--batch", type=int, default=None, help="executor.batch_tasks (ready tasks per batched launch)")
     ap.add_argument("--keep-vt", action="store_true", help="tsqr: keep the V / T factors (the reference's full output set)")
     a = ap.parse_args()
@@ -151,6 +152,15 @@ def main():
             out["TFLOP/s(4n^3/3)"] = round(4 * n ** 3 / 3 / dt / 1e12, 2)
         else:
             out["TFLOP/s(8n^3/3)"] = round(8 * n ** 3 / 3 / dt / 1e12, 2)
+        if a.task_times:
+            # one more run with executor.task_timers: device time by kernel name (a task's bracket on its stream)
+            prog, meta2 = build()
+            prog.config["executor"]["task_timers"] = True
+            for mat in meta2["outputs"] + meta2["intermediates"]:
+                mat.free()
+            run(prog)
+            times = job_runner.collect_task_times(prog)
+            out["task_ms"] = {k: [v["tasks"], round(v["ms"], 2)] for k, v in sorted(times.items(), key=lambda kv: -kv[1]["ms"])}
         print(json.dumps(out))
     elif a.what == "spill":
         from numpywren_amd import matrix
