@@ -11,8 +11,12 @@
 //   for each panel:  qr_panel3_kernel (256-row slabs, one workgroup each, resident for the whole panel: rows in
 //                    registers, one fused reduction and one slab-to-slab hand-off per column) produces the
 //                    panel's reflectors, its PB x PB T block and its R block;
-//                    trailing columns:  W2 -= V_p * (T_p^T * (V_p^T * W2))   -- three MFMA GEMMs
-//   T off-diagonal blocks bottom-up:  T12 = -T1 * (V1^T V2) * T2 with V^T V from one big GEMM.
+//                    trailing columns:  W2 -= V_p * (T_p^T * (V_p^T * W2)), at three widths of reflector (geqrt_core):
+//                    the panel's own (k = 32: streaming MFMA kernels near_vtw / reduce_tt / near_update, ONE launch --
+//                    near_fused_kernel -- for a single or small-batch factorisation), the OB = 128 wide block's and
+//                    the SB wide superblock's (batched GEMMs on helper streams);
+//   T off-diagonal blocks: DLARFT's recurrence per block / superblock column during the factorisation, or bottom-up
+//                    T12 = -T1 * (V1^T V2) * T2 with V^T V from one big GEMM; not at all for T == NULL.
 #include "npw_internal.h"
 
 #include <algorithm>
@@ -912,24 +916,80 @@ __global__ __launch_bounds__(256) void near_fused_kernel(int rows, int pb, int n
         Ts[(i >> 5) * 33 + (i & 31)] = tpre[h];
     }
     // ---- this workgroup's columns: sum of the slabs' partials (fixed order) [+ Wtop], T^T, publish ----
+    // 32 rows x (ce - cb) columns x nslab slabs are about 2048 slots whatever the slab count: 8 per thread, two or three
+    // batches of four loads in flight.  (One lane per element adding up all the slabs in turn was 16 dependent round
+    // trips to the memory side for 64 slabs: 12 of the launch's 22 us.)
+    // (Both waits first poll ONE slot per producer from one wave, with pauses, and only then read everything: thousands of
+    //  lanes polling the same few KB with device-coherent loads queue up in front of the very stores they are waiting for.)
+    if (cb < ce && tid < nslab) {
+        double u0, u1, u2, u3;
+        const slot_t* rep = part + (size_t)tid * (32 * CH) + cb;
+        ld_slots4<1>(rep, rep, rep, rep, true, false, false, false, tag, 8, u0, u1, u2, u3);
+    }
+    __syncthreads();
     {
         const int l = tid >> 3, sub = tid & 7;   // row of X1, 8 lanes per row
-        for (int c = cb + sub; c < ce; c += 8) {
-            const slot_t* base = part + l * CH + c;
+        if (nslab >= 8) {
+            // at most 8 columns: lane `sub` adds the slabs sub, sub + 8, ... of every column, the 8 lanes' sums are then added
+            // in lane order (through LDS: the X2 area is still free)
+            double* const lane_sums = X2s;       // [32][8 columns][8 lanes]
+            const int ngi = (nslab + 7) >> 3, npair = (ce - cb) * ngi;
             double a = 0.0;
-            for (int g = 0; g < nslab; g += 4) {
-                double u0, u1, u2, u3;
-                const bool n1 = g + 1 < nslab, n2 = g + 2 < nslab, n3 = g + 3 < nslab;
-                ld_slots4<4>(base + (size_t)g * (32 * CH), base + (size_t)(n1 ? g + 1 : g) * (32 * CH),
-                             base + (size_t)(n2 ? g + 2 : g) * (32 * CH), base + (size_t)(n3 ? g + 3 : g) * (32 * CH), true, n1, n2, n3,
-                             tag, 1, u0, u1, u2, u3);
-                a += u0;
-                if (n1) a += u1;
-                if (n2) a += u2;
-                if (n3) a += u3;
+            int cur = 0;
+            for (int q0 = 0; q0 < npair; q0 += 4) {
+                const slot_t* ptr[4];
+                bool need[4];
+                int ci[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int q = q0 + e < npair ? q0 + e : npair - 1;
+                    ci[e] = q / ngi;
+                    const int g = sub + 8 * (q - ci[e] * ngi);
+                    need[e] = q0 + e < npair && g < nslab;
+                    ptr[e] = part + (size_t)(need[e] ? g : 0) * (32 * CH) + l * CH + cb + ci[e];
+                }
+                double u[4];
+                ld_slots4<4>(ptr[0], ptr[1], ptr[2], ptr[3], need[0], need[1], need[2], need[3], tag, 1, u[0], u[1], u[2], u[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (q0 + e < npair) {           // (uniform)
+                        if (ci[e] != cur) {         // (uniform) the column changes: the lane's sum of the previous one is complete
+                            lane_sums[(l * 8 + cur) * 8 + sub] = a;
+                            a = 0.0;
+                            cur = ci[e];
+                        }
+                        if (need[e]) a += u[e];
+                    }
+                }
             }
-            if (Wtop && l < pb && c0 + c < nc) a += Wtop[(int64_t)l * ldw + c0 + c];
-            X1s[l * (CH + 1) + c] = a;
+            if (npair > 0) lane_sums[(l * 8 + cur) * 8 + sub] = a;
+            __syncthreads();
+            const int c = cb + sub;
+            if (c < ce) {
+                const double* ls = lane_sums + (l * 8 + sub) * 8;
+                double t = ((((((ls[0] + ls[1]) + ls[2]) + ls[3]) + ls[4]) + ls[5]) + ls[6]) + ls[7];
+                if (Wtop && l < pb && c0 + c < nc) t += Wtop[(int64_t)l * ldw + c0 + c];
+                X1s[l * (CH + 1) + c] = t;
+            }
+        } else {
+            // fewer than 8 slabs (more than 8 columns): a lane per column, its slabs in one or two batches
+            for (int c = cb + sub; c < ce; c += 8) {
+                const slot_t* base = part + l * CH + c;
+                double a = 0.0;
+                for (int g = 0; g < nslab; g += 4) {
+                    double u0, u1, u2, u3;
+                    const bool n1 = g + 1 < nslab, n2 = g + 2 < nslab, n3 = g + 3 < nslab;
+                    ld_slots4<4>(base + (size_t)g * (32 * CH), base + (size_t)(n1 ? g + 1 : g) * (32 * CH),
+                                 base + (size_t)(n2 ? g + 2 : g) * (32 * CH), base + (size_t)(n3 ? g + 3 : g) * (32 * CH), true, n1, n2,
+                                 n3, tag, 1, u0, u1, u2, u3);
+                    a += u0;
+                    if (n1) a += u1;
+                    if (n2) a += u2;
+                    if (n3) a += u3;
+                }
+                if (Wtop && l < pb && c0 + c < nc) a += Wtop[(int64_t)l * ldw + c0 + c];
+                X1s[l * (CH + 1) + c] = a;
+            }
         }
     }
     __syncthreads();
@@ -947,6 +1007,11 @@ __global__ __launch_bounds__(256) void near_fused_kernel(int rows, int pb, int n
         }
     }
     // ---- all of X2 for the chunk ----
+    if (tid < CH) {
+        double u0, u1, u2, u3;
+        ld_slots4<1>(xs + tid, xs + tid, xs + tid, xs + tid, true, false, false, false, tag, 8, u0, u1, u2, u3);
+    }
+    __syncthreads();
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int e0 = tid + 1024 * h;
@@ -1028,11 +1093,8 @@ inline int fused_slab_rows(const Batch& b, int64_t rows, int64_t nc, size_t skca
     const int64_t chunks = ceil_div(nc, 16 * NEAR_NT);
     if (chunks * 2 * 32 * 16 * NEAR_NT > sX2) return 0;
     const int64_t cus = stream_cu_count(s);
-    static const int rs_min = [] {
-        const char* e = getenv("NPW_QR_FUSED_RS");
-        return e ? atoi(e) : 64;
-    }();
-    for (int rs = rs_min; rs <= 1024; rs *= 2) {
+    // (the smallest slab the limits allow: 4096 rows x 224 columns alone 17.4 / 17.9 / 18.3 ms from 64 / 128 / 256 rows up)
+    for (int rs = 64; rs <= 1024; rs *= 2) {
         const int64_t nslab = ceil_div(rows, rs);
         if (nslab <= 16 * NEAR_NT && nslab * chunks * 2 * 32 * 16 * NEAR_NT <= (int64_t)skcap && nslab * chunks * b.count <= cus) return rs;
     }
