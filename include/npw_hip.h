@@ -85,6 +85,10 @@ int npw_stream_create(npw_stream_t* stream, int high_priority);
  * word i/32 = CU i): used to keep a few CUs free of long-running trailing-update workgroups so
  * the latency-bound panel kernels of the critical path always find a slot.               */
 int npw_stream_create_masked(npw_stream_t* stream, const uint32_t* cu_mask, int words);
+/* Also retires what the library keeps per stream (the helper streams of the factorisations, the cached CU count): a later
+ * stream that is handed the same handle starts clean.  The stream must be idle.  Create CU-masked streams once and keep
+ * them: create / destroy cycles of masked streams hang inside the HIP runtime of ROCm 7.2 now and then (observed about
+ * every tenth cycle, with nothing but one GEMM on the stream in between). */
 int npw_stream_destroy(npw_stream_t stream);
 int npw_stream_synchronize(npw_stream_t stream);
 int npw_stream_query(npw_stream_t stream, int* done);

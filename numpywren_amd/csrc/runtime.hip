@@ -26,16 +26,49 @@ int set_error(int code, const char* fmt, ...) {
 using npw::as_stream;
 
 #include <cstdlib>
+#include <map>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 
 namespace npw {
 int stream_cu_count_query(hipStream_t s);
 void forget_stream(hipStream_t s);
+void forget_side_streams(hipStream_t main);
+
+namespace {
+// helper streams per (caller's stream, calling thread): process-wide so that npw_stream_destroy can retire the entries of a
+// stream -- a recycled handle may belong to a stream with another CU mask, and its helpers would carry the old one
+std::mutex g_side_mutex;
+std::unordered_map<hipStream_t, std::map<std::thread::id, SideStream>> g_side_table;
+}  // namespace
+
+void forget_side_streams(hipStream_t main) {
+    std::map<std::thread::id, SideStream> dead;
+    {
+        std::lock_guard<std::mutex> lock(g_side_mutex);
+        auto it = g_side_table.find(main);
+        if (it == g_side_table.end()) return;
+        dead.swap(it->second);
+        g_side_table.erase(it);
+    }
+    for (auto& kv : dead) {   // (work still queued on a helper finishes before the driver releases it)
+        SideStream& e = kv.second;
+        for (hipStream_t st : {e.stream, e.stream2, e.stream3})
+            if (st != nullptr) (void)hipStreamDestroy(st);
+        for (hipEvent_t ev : {e.fork, e.join, e.fork2, e.join2, e.fork3, e.join3})
+            if (ev != nullptr) (void)hipEventDestroy(ev);
+    }
+    (void)hipGetLastError();
+}
 
 int side_stream(hipStream_t main, SideStream** out) {
-    static thread_local std::unordered_map<hipStream_t, SideStream> table;
-    SideStream& e = table[main];
+    SideStream* slot;
+    {
+        std::lock_guard<std::mutex> lock(g_side_mutex);
+        slot = &g_side_table[main][std::this_thread::get_id()];   // (node-based containers: the address is stable)
+    }
+    SideStream& e = *slot;
     if (e.stream == nullptr) {
         // A caller's stream restricted to some compute units (npw_stream_create_masked: the executor's partitions) gets
         // helpers with the SAME mask: what a call forks off must not spill onto the CUs its stream was kept away from.
@@ -290,6 +323,7 @@ int npw_stream_create_masked(npw_stream_t* stream, const uint32_t* cu_mask, int 
 int npw_stream_destroy(npw_stream_t stream) {
     if (stream) {
         npw::forget_stream(as_stream(stream));
+        npw::forget_side_streams(as_stream(stream));
         NPW_HIP_CHECK(hipStreamDestroy(as_stream(stream)));
     }
     return NPW_OK;

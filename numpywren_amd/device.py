@@ -227,6 +227,7 @@ class HipBackend(object):
         self._free = {}      # nbytes -> [ptr]
         self._pending = []   # ({stream: event}, [(ptr, nbytes, streams)]): released buffers waiting for their last users
         self._deferred = []  # (ptr, nbytes, streams): released, no event recorded yet (_flush_deferred)
+        self._dead_streams = set()  # handles of destroyed streams (destroy_stream): no events are recorded on them
         self._event_pool = []
         self.allocated_bytes = 0
         self.pooled_bytes = 0
@@ -271,7 +272,30 @@ class HipBackend(object):
     def create_stream(self, high_priority=False, name=""):
         h = ctypes.c_void_p(0)
         _ffi.check(self.lib.npw_stream_create(ctypes.byref(h), 1 if high_priority else 0), "npw_stream_create")
+        with self._lock:
+            self._dead_streams.discard(h.value)   # (a recycled handle)
         return Stream(h.value, high_priority, name)
+
+    def stream_from_mask(self, mask_words, name=""):
+        """A stream restricted to the compute units whose bits are set in `mask_words` (32-bit words, CU 0 = bit 0 of word 0)."""
+        arr = (ctypes.c_uint32 * len(mask_words))(*mask_words)
+        h = ctypes.c_void_p(0)
+        _ffi.check(self.lib.npw_stream_create_masked(ctypes.byref(h), arr, len(mask_words)), "npw_stream_create_masked")
+        with self._lock:
+            self._dead_streams.discard(h.value)   # (a recycled handle)
+        return Stream(h.value, False, name)
+
+    def destroy_stream(self, stream):
+        """Retire a stream made by create_stream / create_masked_stream (its scratch buffer and the library's helper streams
+        for it go too).  The streams the executor uses live as long as the backend; this is for short-lived ones."""
+        self.stream_sync(stream)
+        with self._lock:
+            ws = (getattr(self, "_stream_ws", None) or {}).pop(stream.handle, None)
+            self._flush_deferred()                  # buffers already released: their events are recorded while the stream lives
+            self._dead_streams.add(stream.handle)   # ... later ones skip it (the stream is drained: nothing left to wait for)
+        del ws
+        _ffi.check(self.lib.npw_stream_destroy(stream.handle), "npw_stream_destroy")
+        stream.handle = None
 
     def create_masked_stream(self, reserve_cus, name=""):
         """A stream restricted to all CUs except `reserve_cus` of them (spread over the XCDs)."""
@@ -289,10 +313,7 @@ class HipBackend(object):
             mask[cu // 32] &= ~(1 << (cu % 32))
             cu += step
             dropped += 1
-        arr = (ctypes.c_uint32 * words)(*mask)
-        h = ctypes.c_void_p(0)
-        _ffi.check(self.lib.npw_stream_create_masked(ctypes.byref(h), arr, words), "npw_stream_create_masked")
-        return Stream(h.value, False, name)
+        return self.stream_from_mask(mask, name)
 
     def chain_streams(self, chain_cus):
         """(chain, rest): a stream restricted to `chain_cus` compute units and one restricted to all the others, so that
@@ -313,10 +334,7 @@ class HipBackend(object):
                     (lead if cu < chain_cus else rest)[cu // 32] |= 1 << (cu % 32)
                 made = []
                 for bits, name in ((lead, "chain"), (rest, "rest")):
-                    arr = (ctypes.c_uint32 * words)(*bits)
-                    h = ctypes.c_void_p(0)
-                    _ffi.check(self.lib.npw_stream_create_masked(ctypes.byref(h), arr, words), "npw_stream_create_masked")
-                    made.append(Stream(h.value, False, name))
+                    made.append(self.stream_from_mask(bits, name))
                 cached = tuple(made)
                 if not hasattr(self, "_chain_streams"):
                     self._chain_streams = {}
@@ -520,6 +538,8 @@ class HipBackend(object):
 
     def _release(self, ptr, nbytes, streams):
         with self._lock:
+            if streams and self._dead_streams:
+                streams = [sh for sh in streams if sh not in self._dead_streams]
             if streams:
                 self._deferred.append((ptr, nbytes, tuple(streams)))
             else:
