@@ -595,10 +595,13 @@ __global__ void move_rows_kernel(int rows, int64_t cols, double* W, int64_t ldw,
 // X2 = T^T (sum of the split-k partial products of V^T W  [+ C]) for pb <= PBMAX rows: the reduction of the partials and
 // the small triangular product in ONE launch (they used to be two on the panel chain's critical path).
 // One thread per column of X2; T is pb x pb upper triangular: X2[i] = sum_{l <= i} T[l][i] X1[l].
+// Rd != NULL (the stacked-triangle update, C = the columns' pb top rows): the rows' final R entries C - X2 go to Rd and C is
+// cleared here as well (each element of C is read and written by one thread only) -- one launch less per panel.
 template <int PBMAX>
-__global__ __launch_bounds__(PBMAX * 16) void reduce_tt_kernel(int pb, int64_t nc, int nsplit, const double* P, const double* C,
+__global__ __launch_bounds__(PBMAX * 16) void reduce_tt_kernel(int pb, int64_t nc, int nsplit, const double* P, double* C,
                                                                int64_t ldc, int64_t sC, const double* Tjj, int64_t ldt,
-                                                               int64_t sT, double* X2, int64_t sX2) {
+                                                               int64_t sT, double* X2, int64_t sX2, double* Rd = nullptr,
+                                                               int64_t ldr = 0, int64_t sR = 0) {
     // block = 16 columns x PBMAX rows: thread (l, j) first sums the partials of X1[l][j] (fixed order), then -- through
     // LDS -- forms X2[l][j] = sum_{i <= l} T[i][l] X1[i][j]
     __shared__ double Ts[PBMAX * (PBMAX + 1)], X1s[PBMAX * 17];
@@ -610,11 +613,14 @@ __global__ __launch_bounds__(PBMAX * 16) void reduce_tt_kernel(int pb, int64_t n
     const int j = threadIdx.x & 15, l = threadIdx.x >> 4;
     const int64_t col = (int64_t)blockIdx.x * 16 + j;
     for (int i = threadIdx.x; i < pb * pb; i += blockDim.x) Ts[(i / pb) * (PBMAX + 1) + (i % pb)] = Tjj[(int64_t)(i / pb) * ldt + (i % pb)];
-    double a = 0.0;
+    double a = 0.0, ctop = 0.0;
     if (l < pb && col < nc) {
         const double* p = P + (int64_t)l * nc + col;
         for (int sidx = 0; sidx < nsplit; ++sidx) a += p[(int64_t)sidx * pb * nc];
-        if (C) a += C[(int64_t)l * ldc + col];
+        if (C) {
+            ctop = C[(int64_t)l * ldc + col];
+            a += ctop;
+        }
     }
     X1s[l * 17 + j] = a;
     __syncthreads();
@@ -622,6 +628,10 @@ __global__ __launch_bounds__(PBMAX * 16) void reduce_tt_kernel(int pb, int64_t n
         double x = 0.0;
         for (int i = 0; i <= l; ++i) x = fma(Ts[i * (PBMAX + 1) + l], X1s[i * 17 + j], x);
         X2[(int64_t)l * nc + col] = x;
+        if (Rd) {
+            Rd[(int64_t)z * sR + (int64_t)l * ldr + col] = ctop - x;
+            C[(int64_t)l * ldc + col] = 0.0;
+        }
     }
 }
 
@@ -1160,7 +1170,7 @@ int apply_panel(const Batch& b, const double* Wp, int64_t ldv, int64_t mp, int64
                            ldv, b.sV, (const double*)W2, ldv, b.sV, skws, rs);
         NPW_LAUNCH_CHECK();
         hipLaunchKernelGGL(reduce_tt_kernel<PB>, dim3((unsigned)ceil_div(nc, 16), (unsigned)b.count), dim3(PB * 16), 0, s, (int)pb, nc,
-                           (int)grid.x, skws, (const double*)nullptr, (int64_t)0, (int64_t)0, Tjj, ldt, b.sT, X2, sX2);
+                           (int)grid.x, skws, (double*)nullptr, (int64_t)0, (int64_t)0, Tjj, ldt, b.sT, X2, sX2);
         NPW_LAUNCH_CHECK();
         hipLaunchKernelGGL(fast ? near_update_kernel<false> : near_update_kernel<true>, grid, dim3(256), 0, s, (int)mp, (int)pb, (int)nc,
                            Wp, ldv, b.sV, (const double*)X2, nc, sX2, W2, ldv, b.sV, rs);
@@ -1181,7 +1191,7 @@ int apply_panel(const Batch& b, const double* Wp, int64_t ldv, int64_t mp, int64
         rc = gemm<double>('T', 'N', pb, nc, mp, 1.0, Wp, ldv, W2, ldv, 0.0, nullptr, 0, X1, nc, g1, s);
         if (rc) return rc;
         hipLaunchKernelGGL(reduce_tt_kernel<PB>, dim3((unsigned)ceil_div(nc, 16), (unsigned)b.count), dim3(PB * 16), 0, s, (int)pb, nc,
-                           nsplit, skws, (const double*)nullptr, (int64_t)0, (int64_t)0, Tjj, ldt, b.sT, X2, sX2);
+                           nsplit, skws, (double*)nullptr, (int64_t)0, (int64_t)0, Tjj, ldt, b.sT, X2, sX2);
         NPW_LAUNCH_CHECK();
     } else if (pb >= 256 && far_nt_form) {
         // superblock reflector: the temporaries are kept TRANSPOSED (X^T = W2^T V, nc x pb), so that the rank-pb update reads
@@ -1270,11 +1280,12 @@ int apply_tri(const Batch& b, const double* Vbot, int64_t ldv, int64_t rows, int
                            Vbot, ldv, b.sV, (const double*)Wbot, ldv, b.sV, skws, rs);
         NPW_LAUNCH_CHECK();
         hipLaunchKernelGGL(reduce_tt_kernel<PB>, dim3((unsigned)ceil_div(nc, 16), (unsigned)b.count), dim3(PB * 16), 0, s, (int)pb, nc,
-                           (int)grid.x, skws, (const double*)Wtop, ldv, b.sV, Tjj, ldt, b.sT, X2, sX2);
+                           (int)grid.x, skws, Wtop, ldv, b.sV, Tjj, ldt, b.sT, X2, sX2, Rdst, ldr, b.sR);   // (the R rows included)
         NPW_LAUNCH_CHECK();
         hipLaunchKernelGGL(fast ? near_update_kernel<false> : near_update_kernel<true>, grid, dim3(256), 0, s, (int)rows, (int)pb,
                            (int)nc, Vbot, ldv, b.sV, (const double*)X2, nc, sX2, Wbot, ldv, b.sV, rs);
         NPW_LAUNCH_CHECK();
+        return NPW_OK;
     } else if (pb <= PB && skws != nullptr && (size_t)pb * nc <= skcap) {
         int nsplit = 1;
         g1.splitk_ws = skws;
@@ -1282,7 +1293,7 @@ int apply_tri(const Batch& b, const double* Vbot, int64_t ldv, int64_t rows, int
         rc = gemm<double>('T', 'N', pb, nc, rows, 1.0, Vbot, ldv, Wbot, ldv, 0.0, nullptr, 0, X1, nc, g1, s);
         if (rc) return rc;
         hipLaunchKernelGGL(reduce_tt_kernel<PB>, dim3((unsigned)ceil_div(nc, 16), (unsigned)b.count), dim3(PB * 16), 0, s, (int)pb, nc,
-                           nsplit, skws, (const double*)Wtop, ldv, b.sV, Tjj, ldt, b.sT, X2, sX2);
+                           nsplit, skws, Wtop, ldv, b.sV, Tjj, ldt, b.sT, X2, sX2);
         NPW_LAUNCH_CHECK();
     } else {
         rc = gemm<double>('T', 'N', pb, nc, rows, 1.0, Vbot, ldv, Wbot, ldv, 1.0, Wtop, ldv, X1, nc, g1, s);
