@@ -1,8 +1,14 @@
 #!/usr/bin/env python
 """bench.py -- BASELINE.json's headline metric on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Either form works for N > 1: without a launcher's environment (no WORLD_SIZE) `--gpus N` starts its own N ranks -- one
+process per GPU under torch.distributed.run on 127.0.0.1, like the reference's drivers launch their own workers
+(experiments/cholesky_experiment.py:170) -- and a line is only ever printed when exactly N ranks joined: `n_gpus` is
+the size of the job that ran, `config.ranks_joined` / `config.devices` / `config.rccl_nranks` are the evidence.
+`--dry-run` stops after the rendezvous and prints who joined (no GPU work).
 
 metric : achieved fp64 TFLOP/s of an N x N tiled Cholesky (4096^2 tiles) = (N^3 / 3) / wall, whole job.
 step   : one complete factorisation (alg_wrappers.cholesky -> LambdaPACK DAG -> HIP-stream executor)
@@ -65,6 +71,60 @@ def _syrk_traffic():
         except Exception:
             continue
     return None, None
+
+
+def _free_port():
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    return port
+
+
+def launch_ranks(gpus, argv):
+    """`--gpus N` (N > 1) outside a launcher: become `python -m torch.distributed.run` with N ranks of this script on
+    this node (one process per GPU; LOCAL_RANK picks the HIP device).  Replaces the current process, so the exit code
+    and rank 0's JSON line are the job's."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs between processes here
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or gpus) // gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+def job_identity(comm, world, rank):
+    """Who joined: every rank's (rank, host, pid, LOCAL_RANK, PCI bus id of its HIP device or None) over the control
+    group, plus the size RCCL itself reports for the payload communicator."""
+    import socket
+    mine = {"rank": rank, "host": socket.gethostname(), "pid": os.getpid(), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+            "device": None, "rccl_nranks": None}
+    try:
+        from numpywren_amd.device import hip_available
+        if hip_available():
+            import ctypes
+            from numpywren_amd import _ffi
+            n = ctypes.c_int(0)
+            _ffi.lib().npw_device_count(ctypes.byref(n))
+            buf = ctypes.create_string_buffer(64)
+            if n.value > 0 and _ffi.lib().npw_device_pci_bus_id(mine["local_rank"] % n.value, buf, 64) == 0:
+                mine["device"] = buf.value.decode()
+    except Exception:
+        pass
+    tr = getattr(comm, "transport", None)
+    if getattr(tr, "handle", None) and hasattr(tr, "lib"):
+        import ctypes
+        w = ctypes.c_int(0)
+        if tr.lib.npw_comm_info(tr.handle, None, ctypes.byref(w), None) == 0:
+            mine["rccl_nranks"] = w.value
+    joined = [None] * world
+    if world > 1:
+        comm.dist.all_gather_object(joined, mine)
+    else:
+        joined = [mine]
+    return joined
 
 
 def build_input(be, nb, b, key, rank=0, world=1, owner=None):
@@ -203,6 +263,7 @@ class Runner(object):
         self.task_timers = False  # N > 1: executor.task_timers in the extra diagnostic step after the timed region
         self.last_dist = None   # what dist.lambdapack_run_distributed returned for the last step (its "diag" entry)
         self.pending = []   # (program, meta) enqueued on the device, not yet waited for
+        self.step_ms = []   # the last timed() call's per-step durations
 
     def settle(self):
         from numpywren_amd import lambdapack as lp
@@ -253,7 +314,21 @@ class Runner(object):
             self.comm.barrier()
         self.be.synchronize()
 
+    def _mark_step(self, program):
+        """A timing event behind everything the step just enqueued (one GPU: steps are pipelined on the device, so the
+        host clock does not see where one ends; the event costs ~4 us of stream time per step)."""
+        be = self.be
+        s0 = (getattr(be, "bulk_streams", None) or be.streams)[0]
+        for ev in (getattr(program, "completion_marks", None) or []) if program is not None else []:
+            be.wait_event(s0, ev)
+        ev = be.new_event(timing=True)
+        be.record(ev, s0)
+        return ev
+
     def timed(self, build, steps, warmup, timers=None):
+        """(elapsed seconds of `steps` runs between two barriers, the last run's meta).  self.step_ms afterwards: each
+        timed step's own duration -- on one GPU from timing events between the steps' completion marks, with several
+        ranks from the host clock around each (synchronous) step, maximum over the ranks."""
         progs = _prebuild(build, steps + warmup)
         for _ in range(warmup):
             self.one_step(*progs.pop(0))
@@ -261,14 +336,43 @@ class Runner(object):
             self.barrier()
             self.be.enable_kernel_timers(timers)
         self.barrier()
+        device_marks = self.comm is None and hasattr(self.be, "new_event")
+        marks = [self._mark_step(None)] if device_marks else []
+        host = []
         t0 = time.time()
         for _ in range(steps):
+            t1 = time.time()
+            program = progs[0][0]
             meta = self.one_step(*progs.pop(0))
+            host.append(time.time() - t1)
+            if device_marks:
+                marks.append(self._mark_step(program))
         self.barrier()
         elapsed = time.time() - t0
         if self.comm is not None:
             elapsed = self.comm.max_over_ranks(elapsed)
+            self.step_ms = [round(1e3 * self.comm.max_over_ranks(h), 3) for h in host]
+        elif device_marks:
+            self.step_ms = [round(self.be.elapsed_ms(a, b), 3) for a, b in zip(marks[:-1], marks[1:])]
+        else:
+            self.step_ms = [round(1e3 * h, 3) for h in host]
         return elapsed, meta
+
+
+def step_stats(step_ms, mean_ms, what="ms_per_step"):
+    """`step_ms` + median + outliers (> 1.5 x the median) for a JSON line whose `ms_per_step` stays the MEAN over the
+    timed bracket (what the driver's own clock checks); a stalled step -- rocm-smi polling on the node has been seen to
+    stall single repetitions by 0.25 - 4 s (profiles/r04_qr_tsqr.md) -- then shows on the line instead of silently
+    halving the figure.  Warns on stderr when mean and median differ by more than 2 %."""
+    if not step_ms:
+        return {}
+    med = float(np.median(step_ms))
+    out = {"step_ms": list(step_ms), what + "_median": round(med, 3),
+           "outliers": [i for i, t in enumerate(step_ms) if t > 1.5 * med]}
+    if med > 0 and abs(mean_ms - med) > 0.02 * med:
+        print(f"[bench] warning: {what} mean {mean_ms:.3f} ms and median {med:.3f} ms differ by "
+              f"{100 * (mean_ms - med) / med:+.1f} % (step_ms {step_ms}); outliers at steps {out['outliers']}", file=sys.stderr)
+    return out
 
 
 def cholesky_residual(be, X, O, nb, full=False):
@@ -304,12 +408,31 @@ def main():
     ap.add_argument("--r-only", action="store_true", help="tsqr: the timed run drops the V / T factors (no task reads them) instead of producing them")
     ap.add_argument("--keep-vt", action="store_true", help="tsqr: (the default since round 4; kept for old command lines)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 65536^2 single-GPU run of the N = 1 line")
+    ap.add_argument("--no-anchor", action="store_true", help="N > 1 chol: skip rank 0's one-GPU run of the same matrix (config.one_gpu_anchor)")
+    ap.add_argument("--dry-run", action="store_true", help="start / join the ranks, print who joined as one JSON line, do no GPU work")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus, sys.argv[1:])     # does not return: this process becomes the launcher of N ranks
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        # never a line whose n_gpus differs from the number of ranks in the job
+        raise SystemExit(f"bench.py --gpus {args.gpus} inside a job of WORLD_SIZE={world}: launch it as "
+                         f"`python bench.py --gpus {args.gpus}` (it starts its own ranks) or under "
+                         f"`python -m torch.distributed.run --nproc-per-node {args.gpus}`")
+    if args.dry_run:
+        from numpywren_amd import dist
+        comm = dist.init_process_group() if (world > 1 or os.environ.get("NUMPYWREN_AMD_FORCE_DIST")) else None
+        joined = job_identity(comm, world, rank)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": args.gpus, "ranks_joined": len([j for j in joined if j]),
+                              "transport": comm.backend if comm is not None else "none", "ranks": joined}))
+        if comm is not None:
+            comm.shutdown()
+        return
     os.environ.pop("NUMPYWREN_AMD_STORE", None)
     if args.streams <= 0:
         # (tsqr: one stream -- a batch of 32 factorisations fills the chip by itself; two batches side by side only fight for
@@ -329,6 +452,7 @@ def main():
     from numpywren_amd import config as npw_config
     chain_cus = int(npw_config.default()["executor"].get("chain_cus", 0) or 0) if (world == 1 and args.streams == 1) else 0
     run = Runner(be, comm, args.streams, args.priority_stream)
+    anchor = None
     par = "1 gpu" if world == 1 else f"{world} gpus, one process each, tiles 2-D block-cyclic, RCCL p2p panel exchange (npw_comm_*)"
 
     if args.workload == "chol":
@@ -336,10 +460,30 @@ def main():
         nb = args.tiles or (4 if world == 1 else 16)
         n = nb * b
         owner = comm.owner_fn(nb) if comm is not None else None
+        if world > 1 and not args.no_anchor:
+            # The anchor of THIS line's strong-scaling point: the same matrix on ONE GPU of this box (rank 0, the plain
+            # one-GPU executor; the other ranks wait at the barrier) -- the N = 1 bench line's `value` is configs[1]'s
+            # 16384^2 matrix, another problem, so a curve must be built from these anchors (or from that line's
+            # `north_star`), never from its `value`.
+            if rank == 0:
+                solo = Runner(be, None, 1)
+                Xa = build_input(be, nb, b, f"bench_chol_anchor_{n}_{b}")
+                ea, ma = solo.timed(lambda: alg_wrappers.cholesky(Xa), 2, 1)
+                anchor = {"what": f"the same {n}x{n} matrix on one GPU (rank 0, before the timed multi-GPU steps)", "steps": 2,
+                          "ms_per_step": round(ea / 2 * 1e3, 3), "tflops": round(2 * (n ** 3 / 3.0) / ea / 1e12, 3),
+                          "step_ms": solo.step_ms}
+                Xa.free()
+                for m_ in ma["outputs"] + ma["intermediates"]:
+                    m_.free()
+                del Xa, ma, solo
+                if hasattr(be, "trim"):
+                    be.trim()
+            comm.barrier()
         X = build_input(be, nb, b, f"bench_chol_{n}_{b}", rank, world, owner)
         # inside the timed region only the roofline kernel is bracketed with events (an event record costs ~4 us of
         # stream time); the other kinds are timed in two extra steps after it, for `kernel_ms`
         elapsed, meta = run.timed(lambda: alg_wrappers.cholesky(X), args.steps, args.warmup, timers=("syrk",))
+        run_step_ms = run.step_ms
         flops = n ** 3 / 3.0
         value = args.steps * flops / elapsed / 1e12
         line = {"metric": "achieved fp64 TFLOP/s, N x N tiled Cholesky (N^3/3 / wall)", "value": round(value, 3),
@@ -402,6 +546,7 @@ def main():
                                       "syrk_frac": round(2.0 * b ** 3 / (float(np.mean(t2)) * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if t2 else None,
                                       "syrk_launches": len(t2),
                                       "residual_all_tiles": cholesky_residual(be, X2, meta2["outputs"][0], nb2, full=True)}
+                line["north_star"].update(step_stats(run.step_ms, line["north_star"]["ms_per_step"], "north_star.ms_per_step"))
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(b)
     elif args.workload == "tsqr":
@@ -425,6 +570,7 @@ def main():
                 X.put_tile(be.fill_random((b, b), 7, j * b, 0), j, 0)
         be.synchronize()
         elapsed, meta = run.timed(lambda: alg_wrappers.tsqr(X), args.steps, args.warmup)
+        run_step_ms = run.step_ms
         flops = 2.0 * m * b * b - 2.0 * b ** 3 / 3
         value = args.steps * flops / elapsed / 1e12
         line = {"metric": "achieved fp64 TFLOP/s, m x n TSQR ((2 m n^2 - 2 n^3 / 3) / wall)", "value": round(value, 3),
@@ -441,6 +587,7 @@ def main():
             line["config"]["r_only_run"] = {"what": "the same program with executor.drop_unread_outputs: only the R factors are produced",
                                             "ms_per_step": round(e2 / args.steps * 1e3, 3),
                                             "tflops": round(args.steps * flops / e2 / 1e12, 3)}
+            line["config"]["r_only_run"].update(step_stats(run.step_ms, line["config"]["r_only_run"]["ms_per_step"], "r_only_run.ms_per_step"))
     else:
         # configs[4]: 32768^2 fp32 GEMM program (fp32 MFMA products, the reference's fp64 add_matrices tree), strong scaling
         nb = args.tiles or 8
@@ -458,6 +605,7 @@ def main():
                     B.put_tile(be.convert(be.fill_random((b, b), 12, i * b, j * b), np.float32), i, j)
         be.synchronize()
         elapsed, meta = run.timed(lambda: alg_wrappers.gemm(A, B), args.steps, args.warmup)
+        run_step_ms = run.step_ms
         value = args.steps * 2.0 * n ** 3 / elapsed / 1e12
         line = {"metric": "achieved fp32 TFLOP/s, N x N GEMM program (2 N^3 / wall)", "value": round(value, 3),
                 "unit": "TFLOP/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -475,10 +623,25 @@ def main():
             fused = args.steps * 2.0 * n ** 3 / e2 / 1e12
             line["config"]["fused_tflops"] = round(fused, 3)
             line["config"]["fused_ms_per_step"] = round(e2 / args.steps * 1e3, 3)
+            line["config"]["fused_step_ms"] = run.step_ms
             line["config"]["fused_pct_fp32_mfma_peak"] = round(100 * fused / 157.3, 2)
             line["config"]["fused_mode"] = "executor.fuse_gemm_reduction: fp32 accumulation in place, result converted to fp64 once"
+    line.update(step_stats(run_step_ms, line["ms_per_step"]))
     if comm is not None:
         line["config"]["transport"] = comm.backend
+        # who ran this: the ranks that joined the control group, the device each one bound, and the size RCCL itself
+        # reports for the payload communicator -- a line is only printed when they all equal --gpus
+        joined = job_identity(comm, world, rank)
+        line["config"]["ranks_joined"] = len([j for j in joined if j])
+        line["config"]["devices"] = [j and j["device"] for j in joined]
+        line["config"]["rccl_nranks"] = joined[0]["rccl_nranks"] if joined and joined[0] else None
+        if line["config"]["ranks_joined"] != args.gpus or (comm.backend == "rccl" and (
+                line["config"]["rccl_nranks"] != args.gpus or len(set(line["config"]["devices"])) != args.gpus)):
+            raise SystemExit(f"bench.py --gpus {args.gpus}: {line['config']['ranks_joined']} ranks joined, RCCL reports "
+                             f"{line['config']['rccl_nranks']}, devices {line['config']['devices']} -- not printing a line "
+                             f"labelled {args.gpus} GPUs")
+        if anchor is not None:
+            line["config"]["one_gpu_anchor"] = anchor
         # The line explains itself (no multi-GPU node was ever available to the builder; the first real run is the driver's):
         # per rank, what the last TIMED step's common walk cost on the host (`host_walk_ms`), how long the host was blocked on
         # the device or the control group, how far the device ran behind it (`drain_ms`), and the bytes moved; then ONE extra

@@ -90,6 +90,10 @@ int npw_stream_create_masked(npw_stream_t* stream, const uint32_t* cu_mask, int 
  * them: create / destroy cycles of masked streams hang inside the HIP runtime of ROCm 7.2 now and then (observed about
  * every tenth cycle, with nothing but one GEMM on the stream in between). */
 int npw_stream_destroy(npw_stream_t stream);
+/* Compute units `stream` may run on (its CU mask; the whole device for a plain stream).  What the resident-grid kernels
+ * (npw_dgeqrt_batched, npw_dtpqrt_batched, npw_dpotrf_lower) size their launches to: a caller that splits a batch so that
+ * it fits asks here, with the same number the library will check. */
+int npw_stream_cu_count(npw_stream_t stream, int* compute_units);
 int npw_stream_synchronize(npw_stream_t stream);
 int npw_stream_query(npw_stream_t stream, int* done);
 int npw_device_synchronize(void);
@@ -384,6 +388,8 @@ int npw_comm_unique_id(void* id_out, size_t id_bytes);
 int npw_comm_init(npw_comm_t* comm, int rank, int world, const void* unique_id);
 int npw_comm_destroy(npw_comm_t comm);
 int npw_comm_abort(npw_comm_t comm);
+/* rank / world: what RCCL itself reports for the live communicator (ncclCommUserRank / ncclCommCount) -- the number of
+ * ranks that really joined, which bench.py puts on every N > 1 line as config.rccl_nranks */
 int npw_comm_info(npw_comm_t comm, int* rank, int* world, npw_stream_t* transport_stream);
 int npw_comm_group_start(npw_comm_t comm);
 int npw_comm_group_end(npw_comm_t comm);

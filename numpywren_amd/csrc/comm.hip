@@ -27,6 +27,8 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -63,6 +65,8 @@ int load_rccl() {
                     bind(h, "ncclSend", r.Send) && bind(h, "ncclRecv", r.Recv) && bind(h, "ncclGroupStart", r.GroupStart) &&
                     bind(h, "ncclGroupEnd", r.GroupEnd) && bind(h, "ncclGetErrorString", r.GetErrorString);
     if (!ok) return set_error(NPW_ERR_UNSUPPORTED, "npw_comm: librccl lacks a required entry point (%s)", dlerror());
+    (void)bind(h, "ncclCommCount", r.CommCount);        // optional: npw_comm_info then reports RCCL's own answer
+    (void)bind(h, "ncclCommUserRank", r.CommUserRank);
     g_rccl = r;
     return NPW_OK;
 }
@@ -165,8 +169,13 @@ int npw_comm_abort(npw_comm_t comm) {
 int npw_comm_info(npw_comm_t comm, int* rank, int* world, npw_stream_t* stream) {
     NPW_REQUIRE(comm != nullptr, "npw_comm_info: NULL communicator");
     Comm* c = as_comm(comm);
-    if (rank) *rank = c->rank;
-    if (world) *world = c->world;
+    // rank / world as RCCL itself reports them for the live communicator (what the ranks that really joined add up to),
+    // not what npw_comm_init was told; an aborted communicator answers with the values it was created with
+    int r = c->rank, w = c->world;
+    if (c->comm != nullptr && g_rccl.CommCount != nullptr) NPW_NCCL_CHECK(g_rccl.CommCount(c->comm, &w));
+    if (c->comm != nullptr && g_rccl.CommUserRank != nullptr) NPW_NCCL_CHECK(g_rccl.CommUserRank(c->comm, &r));
+    if (rank) *rank = r;
+    if (world) *world = w;
     if (stream) *stream = c->stream;
     return NPW_OK;
 }

@@ -1064,7 +1064,9 @@ __global__ __launch_bounds__(256) void near_fused_kernel(int rows, int pb, int n
 inline int near_slab_rows(const Batch& b, int64_t rows, int64_t pb, int64_t nc, size_t skcap) {
     const int64_t chunks = ceil_div(nc, 16 * NEAR_NT);
     int rs = (ceil_div(rows, 256) * chunks * b.count >= 256) ? 256 : 64;
-    while (rs < 4096 && (size_t)(ceil_div(rows, rs) * pb * nc) > skcap) rs *= 2;
+    // (no upper limit on rs: the callers have checked pb * nc <= skcap, so the loop ends at one slab at the latest -- a cap of
+    //  4096 rows overran the scratch for single tall matrices on parts with more than 256 CUs)
+    while ((size_t)(ceil_div(rows, rs) * pb * nc) > skcap) rs *= 2;
     return rs;
 }
 // the fast forms need whole 16-column tiles, a full panel, whole groups of 16 rows and 16-byte aligned rows of V
@@ -1580,7 +1582,10 @@ int geqrt_core(const Batch& b_in, int64_t m, int64_t n, bool tri, double* V, int
         const bool move_near = !tri && near_end - b0 > PB;   // the dense near updates left R rows behind
         const bool last_in_sb = own_end == sb_end;
         const bool far_follows = last_in_sb && (n - mid_end > 0 || far_front < n || (progressive_t && sb0 > 0));
-        if (ob > PB || nmid > 0 || move_near || b0 > sb0 || far_follows) {
+        // (T's block column inside the superblock is only ever read by the superblock's reflector or by the caller: an
+        //  R-only call with a single superblock needs neither -- ADVICE r4)
+        const bool t_col = b0 > sb0 && (want_t || nsb > 1);
+        if (ob > PB || nmid > 0 || move_near || t_col || far_follows) {
             // block reflector on the side stream: T_b from the Gram matrix of the block's columns, then the mid update
             NPW_HIP_CHECK(hipEventRecord(side->fork, s));   // (behind the wait for join2: covers the second helper stream too)
             NPW_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
@@ -1632,7 +1637,7 @@ int geqrt_core(const Batch& b_in, int64_t m, int64_t n, bool tri, double* V, int
             if (nmid <= 0) NPW_HIP_CHECK(hipEventRecord(side->join, side->stream));
             // T's block column of this block inside its superblock (rows sb0 .. b0): T_S has to be complete before the
             // superblock's reflector is applied
-            if (b0 > sb0) {
+            if (t_col) {
                 int rc = t_column(Tq, sb0, b0, ob, q.X1, q.X2, q.sX, q.G, q.sG, side->stream);
                 if (rc) return rc;
             }

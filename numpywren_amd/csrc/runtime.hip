@@ -329,6 +329,12 @@ int npw_stream_destroy(npw_stream_t stream) {
     return NPW_OK;
 }
 
+int npw_stream_cu_count(npw_stream_t stream, int* compute_units) {
+    NPW_REQUIRE(compute_units != nullptr, "npw_stream_cu_count: NULL argument");
+    *compute_units = npw::stream_cu_count(static_cast<hipStream_t>(stream));
+    return NPW_OK;
+}
+
 int npw_stream_synchronize(npw_stream_t stream) {
     NPW_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
     return NPW_OK;

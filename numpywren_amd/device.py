@@ -229,6 +229,8 @@ class HipBackend(object):
         self._deferred = []  # (ptr, nbytes, streams): released, no event recorded yet (_flush_deferred)
         self._dead_streams = set()  # handles of destroyed streams (destroy_stream): no events are recorded on them
         self._event_pool = []
+        self._timing_pool = []      # timing-enabled events, kept apart from the ordering events above
+        self._timing_events = set()
         self.allocated_bytes = 0
         self.pooled_bytes = 0
         self.peak_bytes = 0
@@ -344,6 +346,12 @@ class HipBackend(object):
                     self._partition_names[st.handle] = st.name
         return cached
 
+    def stream_cus(self, stream=None):
+        """Compute units `stream` may run on (npw_stream_cu_count: its CU mask, or the whole device)."""
+        n = ctypes.c_int(0)
+        _ffi.check(self.lib.npw_stream_cu_count(self._sh(stream), ctypes.byref(n)), "npw_stream_cu_count")
+        return n.value
+
     def chol_resident_cus(self, n):
         """Compute units a stream must offer for `chol` of an n x n tile (npw_dpotrf_lower_resident_cus)."""
         return int(self.lib.npw_dpotrf_lower_resident_cus(int(n)))
@@ -356,17 +364,22 @@ class HipBackend(object):
         return stream
 
     def new_event(self, timing=False):
-        if not timing:
-            with self._lock:
-                if self._event_pool:
-                    return self._event_pool.pop()
+        """An event from the pool of its kind.  Timing events have their own pool: they are slower to record than the
+        plain ordering events, so one must never be handed out as the other."""
+        with self._lock:
+            pool = self._timing_pool if timing else self._event_pool
+            if pool:
+                return pool.pop()
         h = ctypes.c_void_p(0)
         _ffi.check(self.lib.npw_event_create(ctypes.byref(h), 1 if timing else 0), "npw_event_create")
+        if timing:
+            with self._lock:
+                self._timing_events.add(h.value)
         return h.value
 
     def recycle_event(self, ev):
         with self._lock:
-            self._event_pool.append(ev)
+            (self._timing_pool if ev in self._timing_events else self._event_pool).append(ev)
 
     def record(self, ev, stream=None):
         _ffi.check(self.lib.npw_event_record(ev, self._sh(stream)), "npw_event_record")
@@ -447,6 +460,8 @@ class HipBackend(object):
             out[name] = []
             for a, b, count in pairs:
                 out[name] += [self.elapsed_ms(a, b) / count] * count
+                self.recycle_event(a)
+                self.recycle_event(b)
         self.kernel_timers = None
         return out
 
@@ -1261,9 +1276,11 @@ class HipBackend(object):
         m, n = As[0].shape
         if len(As) == 1 or m < n or any(a.shape != (m, n) for a in As):
             return [self.geqrt(a, stream, want_t=want_t) for a in As]
-        # the panel kernel's workgroups (count x 256-row slabs) wait for each other: keep a batch within what the
-        # device holds at once (2 workgroups per CU)
-        cap = max(1, (2 * self.compute_units) // ((m + 255) // 256))
+        # the panel kernel's workgroups wait for each other, so a batch has to be resident at once.  The library's rule
+        # (qr.hip geqrt_core) is count x ceil(rows / 512) workgroups on 2 slots per compute unit OF THE STREAM -- a masked
+        # stream of the executor offers fewer than the device; batches are kept at half of that (one 256-row slab per
+        # workgroup: 32 tiles of 4096 rows on the whole chip, the size every measurement of the batched form was made at)
+        cap = max(1, (2 * self.stream_cus(sh)) // ((m + 255) // 256))
         if len(As) > cap:
             out = []
             for i in range(0, len(As), cap):
@@ -1300,6 +1317,13 @@ class HipBackend(object):
         for a, c in pairs:
             if a.shape != (n, n) or c.shape != (n, n):
                 raise ValueError(f"tpqrt: expected pairs of {n} x {n} tiles, got {a.shape} over {c.shape}")
+        # (same residency rule as geqrt_batched; a stacked-triangle panel touches at most n + 32 rows)
+        cap = max(1, (2 * self.stream_cus(sh)) // ((n + 32 + 511) // 512))
+        if len(pairs) > cap:
+            out = []
+            for i in range(0, len(pairs), cap):
+                out.extend(self.tpqrt_batched(pairs[i:i + cap], stream, want_t=want_t, want_v=want_v))
+            return out
         count = len(pairs)
         vb, tb = 2 * n * n * 8, n * n * 8
         wsb = _round_up(max(16, self.lib.npw_dtpqrt_batched_workspace_bytes(count, n)), 256)

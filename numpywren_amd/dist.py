@@ -683,7 +683,7 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
         comm.flush()
         be.synchronize()
         t_drained = time.time()
-        ok = job_runner.check_info_flags(program, be) and job_runner.check_handoffs(program, be)
+        ok = job_runner.settle_checks(program, be)
         # a failure on any rank fails the program everywhere
         bad = comm.max_over_ranks(0.0 if ok and program.program_status() != lp.PS.EXCEPTION else 1.0)
         program._defer_success = False

@@ -565,29 +565,43 @@ def _info_sink(program, task):
 lp.LambdaPackProgram.info_flags_sink = lambda self, task: _info_sink(self, task)
 
 
-def collect_task_times(program):
-    """{kernel name: {"tasks": n, "ms": total device time}} of the tasks run with executor.task_timers since the last call
-    (synchronises the device; with several streams the brackets of concurrent tasks overlap, so the sum can exceed the
-    wall time)."""
+def _drain_task_times(program, synchronise=True):
+    """Turn the pending (name, start event, stop event, count) records of executor.task_timers into totals on the program
+    and hand the events back to the backend's timing pool -- called when a run settles, so that neither the records nor
+    their events pile up over runs nobody collects."""
     from .device import get_backend
     be = get_backend()
     records = program.__dict__.get("_task_times") or []
-    out = {}
+    totals = program.__dict__.setdefault("_task_time_totals", {})
     if records:
-        be.synchronize()
+        if synchronise:
+            be.synchronize()
         for name, ev0, ev1, count in records:
-            slot = out.setdefault(name, {"tasks": 0, "ms": 0.0})
+            slot = totals.setdefault(name, {"tasks": 0, "ms": 0.0})
             slot["tasks"] += count
             slot["ms"] += be.elapsed_ms(ev0, ev1)
             be.recycle_event(ev0)
             be.recycle_event(ev1)
         del records[:]
+    return totals
+
+
+def collect_task_times(program):
+    """{kernel name: {"tasks": n, "ms": total device time}} of the tasks run with executor.task_timers since the last call
+    (synchronises the device; with several streams the brackets of concurrent tasks overlap, so the sum can exceed the
+    wall time)."""
+    out = dict(_drain_task_times(program))
+    program.__dict__["_task_time_totals"] = {}
     return out
 
 
 def check_handoffs(program, be):
     """A run with Householder factorisations: did a hand-off wait inside the panel kernel expire (libnpw_hip.so bounds them
-    so that a lost hand-off cannot hang the GPU)?  Then some factorisation returned undefined numbers: fail the program."""
+    so that a lost hand-off cannot hang the GPU)?  Then some factorisation returned undefined numbers: fail the program.
+    The counter is one per PROCESS (a device global): with two wait=False programs in flight, or direct be.geqrt callers
+    beside a program, an expired wait is charged to whichever run settles first -- the attribution is per process, not
+    per program; what matters is that it is never lost.  Callers evaluate this check whatever the info flags said
+    (`settle_checks`), so a failing run does not leave its count behind for the next one."""
     kinds = getattr(program.program, "_kernels", {}) or {}
     if not hasattr(be, "qr_handoff_timeouts") or not any(getattr(k, "_npw_handoff", False) for k in kinds.values()):
         return True
@@ -614,6 +628,14 @@ def check_info_flags(program, be, stream=None):
             program.handle_exception(np.linalg.LinAlgError(msg), tb="", expr_idx=node[0], var_values=node[1])
             return False
     return True
+
+
+def settle_checks(program, be, stream=None):
+    """Both deferred checks of a settled run, ALWAYS both (no short-circuit: the hand-off counter must be read and reset
+    even when the info flags already failed the program)."""
+    flags_ok = check_info_flags(program, be, stream) if stream is not None else check_info_flags(program, be)
+    handoffs_ok = check_handoffs(program, be)
+    return flags_ok and handoffs_ok
 
 
 def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, timeout=200, idle_timeout=5,
@@ -770,13 +792,15 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
             try:
                 if marks is None or wait:
                     be.synchronize()
-                    ok = check_info_flags(program, be) and check_handoffs(program, be)
+                    ok = settle_checks(program, be)
                     for ev in (marks or []):
                         be.recycle_event(ev)
                 else:
                     for ev in marks:
                         be.event_sync(ev)   # (events stay alive: a later run may still be told to wait for them)
-                    ok = check_info_flags(program, be, be.flag_stream()) and check_handoffs(program, be)
+                    ok = settle_checks(program, be, be.flag_stream())
+                if ex.task_timers:
+                    _drain_task_times(program, synchronise=False)   # (their events precede the marks just waited for)
                 program._defer_success = False
                 if ok and program._success_pending and program.program_status() == lp.PS.RUNNING:
                     program.return_success()

@@ -44,6 +44,9 @@ def test_bench_runs_and_prints_one_json_line():
     line = json.loads(lines[0])
     _check_line(line)
     assert line["config"]["residual_all_tiles"] < 1e-13
+    # every timed step's own duration (timing events between the steps' completion marks), its median, and the outliers
+    assert len(line["step_ms"]) == 2 and all(t > 0 for t in line["step_ms"]) and line["ms_per_step_median"] > 0
+    assert abs(sum(line["step_ms"]) / 2 - line["ms_per_step"]) < 0.5 * line["ms_per_step"] and isinstance(line["outliers"], list)
     assert line["roofline"]["traffic"] is None            # PMC figure only applies to the 4096^2 tile
     assert "north_star" not in line                       # only with the full-size tile
 
@@ -89,6 +92,9 @@ def test_bench_distributed_path_on_one_gpu():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["config"]["transport"] == "rccl" and line["value"] > 0
+    # the evidence of who ran it: one rank joined, RCCL itself reports a communicator of one, one PCI device
+    assert line["config"]["ranks_joined"] == 1 == line["config"]["rccl_nranks"] and len(line["config"]["devices"]) == 1
+    assert line["config"]["devices"][0] and len(line["step_ms"]) == 1
 
 
 @pytest.mark.gpu
@@ -124,3 +130,62 @@ def test_bench_two_ranks_on_one_gpu(workload, extra, port):
     assert line["config"]["predicted"]["tflops_by_gpus"]["8"] > 0 and "not a measurement" in line["config"]["predicted"]["source"]
     if workload == "chol":
         assert line["scaling"] == "strong" and sum(d["timed_step"]["bytes_sent"] for d in line["per_rank"]) > 0
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher: the script becomes the launcher, two ranks join the
+    control group, and rank 0 reports exactly those two.  --dry-run stops after the rendezvous, so this runs without a GPU
+    (gloo control group, host transport)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"]
+    out = subprocess.run(cmd, cwd=ROOT, env=_clean_env(NUMPYWREN_AMD_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["dry_run"] is True and line["n_gpus"] == 2 == line["ranks_joined"] == len(line["ranks"])
+    assert sorted(r["rank"] for r in line["ranks"]) == [0, 1] and sorted(r["local_rank"] for r in line["ranks"]) == [0, 1]
+    assert len({r["pid"] for r in line["ranks"]}) == 2          # one process per rank
+
+
+@pytest.mark.parametrize("world", ["1", "4"])
+def test_bench_refuses_a_job_of_another_size(world):
+    """--gpus N inside a job whose WORLD_SIZE is not N never prints a line (it used to run the one-GPU workload and label
+    it n_gpus = N)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"]
+    out = subprocess.run(cmd, cwd=ROOT, env=_clean_env(WORLD_SIZE=world, RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE=" + world in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_step_stats_flags_a_stalled_step(capsys):
+    sys.path.insert(0, ROOT)
+    import bench
+    s = bench.step_stats([26.5, 26.7, 80.0, 26.6, 26.4], 37.24)
+    assert s["ms_per_step_median"] == 26.6 and s["outliers"] == [2] and s["step_ms"][2] == 80.0
+    assert "differ" in capsys.readouterr().err
+    assert bench.step_stats([26.5, 26.6], 26.55)["outliers"] == [] and capsys.readouterr().err == ""
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_without_a_launcher_on_one_gpu():
+    """The same self-launch end to end on the GPU box: `python bench.py --gpus 2` with no WORLD_SIZE runs the two-rank
+    Cholesky (ranks share the box's one GPU: host-staged payloads, allowed knowingly through NUMPYWREN_AMD_DIST_BACKEND)
+    and the line carries the evidence of who ran it plus rank 0's one-GPU anchor of the same matrix."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--tile", "256", "--tiles", "4"]
+    out = subprocess.run(cmd, cwd=ROOT, env=_clean_env(NUMPYWREN_AMD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 == line["config"]["ranks_joined"] == len(line["per_rank"]) == len(line["config"]["devices"])
+    assert line["config"]["transport"] == "host" and line["config"]["rccl_nranks"] is None
+    assert len(line["step_ms"]) == 2 and line["ms_per_step_median"] > 0 and line["outliers"] in ([], [0], [1])
+    a = line["config"]["one_gpu_anchor"]
+    assert a["tflops"] > 0 and a["ms_per_step"] > 0 and len(a["step_ms"]) == 2
