@@ -90,10 +90,13 @@ int npw_stream_create_masked(npw_stream_t* stream, const uint32_t* cu_mask, int 
  * them: create / destroy cycles of masked streams hang inside the HIP runtime of ROCm 7.2 now and then (observed about
  * every tenth cycle, with nothing but one GEMM on the stream in between). */
 int npw_stream_destroy(npw_stream_t stream);
-/* Compute units `stream` may run on (its CU mask; the whole device for a plain stream).  What the resident-grid kernels
- * (npw_dgeqrt_batched, npw_dtpqrt_batched, npw_dpotrf_lower) size their launches to: a caller that splits a batch so that
- * it fits asks here, with the same number the library will check. */
-int npw_stream_cu_count(npw_stream_t stream, int* compute_units);
+/* compute_units: the compute units `stream` may run on (its CU mask; the whole device for a plain stream).
+ * resident_units: what the resident-grid kernels (npw_dgeqrt_batched, npw_dtpqrt_batched, npw_dpotrf_lower: every workgroup
+ * of a launch waits for the others) size their launches to and check against -- compute_units minus the ones left to RCCL's
+ * transfer kernels while a communicator of npw_comm_init is live in this process ($NPW_COMM_RESERVE_CUS, default 64 -- RCCL's channel limit: a
+ * send / receive workgroup parked on a CU waiting for its peer is not part of any stream's mask).  A caller that splits a
+ * batch so that it fits asks here, with the same number the library will check.  Either pointer may be NULL. */
+int npw_stream_cu_count(npw_stream_t stream, int* compute_units, int* resident_units);
 int npw_stream_synchronize(npw_stream_t stream);
 int npw_stream_query(npw_stream_t stream, int* done);
 int npw_device_synchronize(void);

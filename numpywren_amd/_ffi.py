@@ -49,7 +49,7 @@ PROTOTYPES = {
     "npw_stream_create": (c_int, [POINTER(_vp), c_int]),
     "npw_stream_create_masked": (c_int, [POINTER(_vp), POINTER(ctypes.c_uint32), c_int]),
     "npw_stream_destroy": (c_int, [_vp]),
-    "npw_stream_cu_count": (c_int, [_vp, POINTER(c_int)]),
+    "npw_stream_cu_count": (c_int, [_vp, POINTER(c_int), POINTER(c_int)]),
     "npw_stream_synchronize": (c_int, [_vp]),
     "npw_stream_query": (c_int, [_vp, POINTER(c_int)]),
     "npw_device_synchronize": (c_int, []),

@@ -33,12 +33,21 @@ DEFAULTS = {
         # factorisation is done (job_runner.LambdaPackExecutor.run_chain).  64 = the 63 panel workgroups of a 4096^2
         # tile + 1; the other 192 CUs hold a 1024-tile syrk in exactly 3 rounds.  0 = off.  $NUMPYWREN_AMD_CHAIN_CUS.
         "chain_cus": 64,
+        # The host-DRAM tier (residency.py) reads the static DAG: victims by farthest next read and copies back ahead of the
+        # readers (False: round 1's LRU, restores on demand); tiles of the next `spill_prefetch_tasks` tasks are brought
+        # back early; while the tier is at work (a byte budget is set, or tiles have been pushed out) the batches of the
+        # THROUGHPUT kernels (syrk, trsm, gemm) are at most `spill_batch_tasks` tasks: a batched launch waits for the
+        # copy-in of ALL its operands, so 16 trailing updates per launch make copies and kernels take turns (32768^2
+        # Cholesky, 12 tiles of budget: 404 ms with batches of 32, 328 with 8; 24 tiles: 264 / 204 with 4).
+        "spill_plan": True,
+        "spill_prefetch_tasks": 2,
+        "spill_batch_tasks": 8,
     },
     "store": {
         "tier": "hbm",           # "hbm" (device memory) or "host" (pinned/pageable host memory)
         "device_pool": True,
-        # Byte budget for tiles stored in HBM (int or "200G"); beyond it the least-recently-used tiles move to pinned
-        # host DRAM and come back on their next read (residency.py).  None: no budget -- tiles are only pushed out
+        # Byte budget for tiles stored in HBM (int or "200G"); beyond it the tiles whose next read is farthest in the task
+        # sequence move to pinned host DRAM and come back ahead of that read (residency.py).  None: no budget -- tiles are only pushed out
         # when a device allocation fails.  $NUMPYWREN_AMD_HBM_BUDGET overrides.
         "hbm_budget_bytes": None,
     },

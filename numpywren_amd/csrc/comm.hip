@@ -136,6 +136,7 @@ int npw_comm_init(npw_comm_t* comm_out, int rank, int world, const void* unique_
         delete c;
         return set_error(NPW_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, g_rccl.GetErrorString(r));
     }
+    comm_live_changed(+1);   // resident-grid kernels now leave CUs to the transfer kernels (resident_cu_count)
     *comm_out = c;
     return NPW_OK;
 }
@@ -144,7 +145,10 @@ int npw_comm_destroy(npw_comm_t comm) {
     if (comm == nullptr) return NPW_OK;
     Comm* c = as_comm(comm);
     (void)hipStreamSynchronize(c->stream);
-    if (c->comm != nullptr) (void)g_rccl.CommDestroy(c->comm);
+    if (c->comm != nullptr) {
+        (void)g_rccl.CommDestroy(c->comm);
+        comm_live_changed(-1);
+    }
     // The transport stream is NOT destroyed: tiles that travelled on it remember its handle and record their release
     // events on it long after the communicator is gone (one idle stream per communicator for the life of the process).
     delete c;
@@ -161,6 +165,7 @@ int npw_comm_abort(npw_comm_t comm) {
     if (c->comm != nullptr) {
         ncclComm_t dead = c->comm;
         c->comm = nullptr;
+        comm_live_changed(-1);
         NPW_NCCL_CHECK(g_rccl.CommAbort(dead));
     }
     return NPW_OK;

@@ -1335,8 +1335,8 @@ int potrf_right(int64_t n, double* A, int64_t lda, int32_t* info, double* Winv, 
     static std::atomic<unsigned long long> call_counter{
         (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() & 0x3fffffffULL};
     const unsigned long long call_tag = (call_counter.fetch_add(1) + 1) << 20;
-    NPW_REQUIRE(potrf_resident_wgs(n) <= stream_cu_count(s), "potrf: the panel chain of a %lld^2 tile needs %lld resident workgroups, the stream has %d CUs",
-                (long long)n, (long long)potrf_resident_wgs(n), stream_cu_count(s));
+    NPW_REQUIRE(potrf_resident_wgs(n) <= resident_cu_count(s), "potrf: the panel chain of a %lld^2 tile needs %lld resident workgroups, the stream offers %d CUs",
+                (long long)n, (long long)potrf_resident_wgs(n), resident_cu_count(s));
     for (int64_t j0 = 0; j0 < n; j0 += NB) {
         const int64_t nb = (n - j0 < NB) ? n - j0 : NB;
         double* Ajj = A + j0 * lda + j0;
@@ -1392,7 +1392,7 @@ int potrf_lookahead(int64_t n, double* A, int64_t lda, int32_t* info, double* Wi
     static std::atomic<unsigned long long> call_counter{
         (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() & 0x3fffffffULL};
     const unsigned long long call_tag = (call_counter.fetch_add(1) + 1) << 20;
-    const int num_cus = stream_cu_count(s);
+    const int num_cus = resident_cu_count(s);   // (the stream's CUs, minus the ones left to RCCL while a communicator is live)
     for (int64_t jb = 0; jb < steps; ++jb) {
         const int64_t j0 = jb * NB;
         const int64_t m = n - j0 - NB;

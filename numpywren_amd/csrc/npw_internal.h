@@ -100,5 +100,12 @@ int side_stream(hipStream_t main, SideStream** out);
 // (npw_stream_create_masked: the executor's chain partition).
 int stream_cu_count(hipStream_t s);
 int device_cu_count();
+// What a RESIDENT-GRID kernel (every workgroup of a launch waits for the others: the QR panel kernels, the Cholesky panel
+// chain, the fused near update) may count on: the stream's compute units minus the ones set aside for RCCL's transfer
+// kernels while a communicator is live in this process (comm.hip: a send / receive kernel parked on a CU waiting for its
+// peer holds registers and LDS there for as long as the peer takes, and is not part of the stream's CU mask).
+int resident_cu_count(hipStream_t s);
+void comm_live_changed(int delta);   // comm.hip: +1 on npw_comm_init, -1 on destroy / abort
+int comm_reserved_cus();             // 0 without a live communicator, else $NPW_COMM_RESERVE_CUS (default: see runtime.hip)
 
 }  // namespace npw

@@ -1104,7 +1104,7 @@ inline int fused_slab_rows(const Batch& b, int64_t rows, int64_t nc, size_t skca
     if (!near_fused_on || tag == 0 || b.count >= 8) return 0;
     const int64_t chunks = ceil_div(nc, 16 * NEAR_NT);
     if (chunks * 2 * 32 * 16 * NEAR_NT > sX2) return 0;
-    const int64_t cus = stream_cu_count(s);
+    const int64_t cus = resident_cu_count(s);
     // (the smallest slab the limits allow: 4096 rows x 224 columns alone 17.4 / 17.9 / 18.3 ms from 64 / 128 / 256 rows up)
     for (int rs = 64; rs <= 1024; rs *= 2) {
         const int64_t nslab = ceil_div(rows, rs);
@@ -1333,11 +1333,11 @@ int geqrt_core(const Batch& b_in, int64_t m, int64_t n, bool tri, double* V, int
     {
         // every workgroup of a panel launch waits for the others: the whole launch has to be resident on the stream's CUs
         // (a CU-masked stream of the executor offers fewer than the chip: refuse instead of timing out with wrong numbers)
-        const int64_t slots = 2 * (int64_t)stream_cu_count(s);
+        const int64_t slots = 2 * (int64_t)resident_cu_count(s);   // (minus RCCL's share while a communicator is live)
         const int64_t rows_max = tri ? n + PB : m;
         const int64_t need = (int64_t)b_in.count * ceil_div(rows_max, 2 * SLAB);
         NPW_REQUIRE(need <= slots, "batched QR: %lld x %lld rows need %lld resident panel workgroups, the stream's %d compute "
-                    "units hold %lld", (long long)b_in.count, (long long)rows_max, (long long)need, stream_cu_count(s), (long long)slots);
+                    "units hold %lld", (long long)b_in.count, (long long)rows_max, (long long)need, resident_cu_count(s), (long long)slots);
     }
     // (small batches are bound by the latency of the panel chain, not by GEMM throughput: the extra launches and waits of
     //  the third level cost them time -- 4096^2: x1 17.6 ms without it, 19.9 / 27 ms with SB = 256 / 128; x4 26.3 vs 29.0)
@@ -1393,7 +1393,7 @@ int geqrt_core(const Batch& b_in, int64_t m, int64_t n, bool tri, double* V, int
         const char* e = getenv("NPW_QR_PANEL_MAX_WGS");
         return e ? (int64_t)atoll(e) : (int64_t)PANEL_MAX_WGS;
     }();
-    const int64_t panel_max_wgs = std::min<int64_t>(panel_wgs_env, 2 * (int64_t)stream_cu_count(s));   // (default: half of the chip's slots)
+    const int64_t panel_max_wgs = std::min<int64_t>(panel_wgs_env, 2 * (int64_t)resident_cu_count(s));   // (default: half of the chip's slots)
     bool far_in_flight = false;   // a far update has been issued: the next `mid` update waits for its first part
 
     // T[r0:c0, c0:c0+w] = -T[r0:c0, r0:c0] * (V[:, r0:c0]^T V[:, c0:c0+w]) * T[c0:c0+w, c0:c0+w]   (DLARFT's recurrence for a

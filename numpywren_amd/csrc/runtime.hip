@@ -27,6 +27,7 @@ using npw::as_stream;
 
 #include <cstdlib>
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -135,6 +136,31 @@ int stream_cu_count(hipStream_t s) {
 void forget_stream(hipStream_t s) {
     std::lock_guard<std::mutex> lock(g_cu_cache_mutex);
     g_cu_cache.erase(s);
+}
+
+namespace {
+std::atomic<int> g_live_comms{0};
+constexpr int COMM_RESERVE_DEFAULT = 64;
+}  // namespace
+
+void comm_live_changed(int delta) { g_live_comms.fetch_add(delta); }
+
+int comm_reserved_cus() {
+    // RCCL launches ONE kernel per grouped exchange with one workgroup per channel it uses; measured on this part
+    // (profiles/r05_rccl_headroom.md, rocprofv3 kernel trace): ncclDevKernel_Generic_1 with 24 workgroups of 256 threads
+    // for one send / receive pair, 64 -- RCCL's channel limit on this part -- for a group of 8 pairs; 37 KiB of LDS and
+    // 124 VGPRs each.  One compute unit per channel is set aside: a parked transfer workgroup takes one of the CU's two big
+    // slots AND enough LDS that a 133 KiB Cholesky workgroup no longer fits beside it.
+    static const int reserve = [] {
+        const char* e = getenv("NPW_COMM_RESERVE_CUS");
+        return e ? atoi(e) : COMM_RESERVE_DEFAULT;
+    }();
+    return g_live_comms.load() > 0 ? reserve : 0;
+}
+
+int resident_cu_count(hipStream_t s) {
+    const int cus = stream_cu_count(s), keep = comm_reserved_cus();
+    return cus - keep > 0 ? cus - keep : 1;
 }
 
 int device_cu_count() {
@@ -329,9 +355,9 @@ int npw_stream_destroy(npw_stream_t stream) {
     return NPW_OK;
 }
 
-int npw_stream_cu_count(npw_stream_t stream, int* compute_units) {
-    NPW_REQUIRE(compute_units != nullptr, "npw_stream_cu_count: NULL argument");
-    *compute_units = npw::stream_cu_count(static_cast<hipStream_t>(stream));
+int npw_stream_cu_count(npw_stream_t stream, int* compute_units, int* resident_units) {
+    if (compute_units != nullptr) *compute_units = npw::stream_cu_count(static_cast<hipStream_t>(stream));
+    if (resident_units != nullptr) *resident_units = npw::resident_cu_count(static_cast<hipStream_t>(stream));
     return NPW_OK;
 }
 

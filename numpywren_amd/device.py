@@ -26,6 +26,28 @@ _F64 = np.dtype(np.float64)
 _F32 = np.dtype(np.float32)
 
 
+def _host_memory_limit():
+    """Bytes of host memory this process may use: the smaller of the machine's RAM and the container's cgroup limit."""
+    limit = None
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemTotal:"):
+                    limit = int(line.split()[1]) * 1024
+                    break
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            with open(path) as f:
+                v = f.read().strip()
+            if v.isdigit() and (limit is None or int(v) < limit):
+                limit = int(v)
+        except Exception:
+            pass
+    return limit if limit else 1 << 40
+
+
 def _round_up(n, m):
     return (n + m - 1) // m * m
 
@@ -119,7 +141,7 @@ class SpilledTile(object):
 
     @property
     def nbytes(self):
-        return int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        return _prod(self.shape) * self.dtype.itemsize   # (plain ints: np.prod was a fifth of the executor's host time per task)
 
     def __repr__(self):
         return f"SpilledTile(shape={self.shape}, dtype={self.dtype})"
@@ -138,6 +160,13 @@ class _Ready(tuple):
             self.backend.recycle_event(self[0])
         except Exception:
             pass
+
+
+def _prod(shape):
+    n = 1
+    for x in shape:
+        n *= x
+    return n
 
 
 class DeviceTile(object):
@@ -163,7 +192,7 @@ class DeviceTile(object):
 
     @property
     def nbytes(self):
-        return int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        return _prod(self.shape) * self.dtype.itemsize   # (plain ints: np.prod was a fifth of the executor's host time per task)
 
     @property
     def ndim(self):
@@ -171,7 +200,7 @@ class DeviceTile(object):
 
     @property
     def size(self):
-        return int(np.prod(self.shape, dtype=np.int64))
+        return _prod(self.shape)
 
     def rows_cols(self):
         """2-D view (rows, cols) of the tile: leading dims collapse into rows."""
@@ -179,12 +208,12 @@ class DeviceTile(object):
             return 1, 1
         if len(self.shape) == 1:
             return 1, self.shape[0]
-        return int(np.prod(self.shape[:-1], dtype=np.int64)), self.shape[-1]
+        return _prod(self.shape[:-1]), self.shape[-1]
 
     def reshaped(self, shape):
         """A second handle on the same buffer with a different (same-size) shape."""
         shape = tuple(int(s) for s in shape)
-        assert int(np.prod(shape, dtype=np.int64)) == self.size, (shape, self.shape)
+        assert _prod(shape) == self.size, (shape, self.shape)
         t = DeviceTile(self.buf, shape, self.dtype, self.offset)
         t.ready = self.ready
         t.zero_flag = self.zero_flag
@@ -250,6 +279,11 @@ class HipBackend(object):
         self._spill_streams = None
         self._pinned_free = {}   # nbytes -> [(ptr, event or None)]
         self.pinned_bytes = 0
+        self.pinned_limit_bytes = int(os.environ.get("NUMPYWREN_AMD_PINNED_LIMIT", 64 << 30))   # ceiling of the pinned pool's growth
+        # ... and what the host tier may hold at all: pinned memory counts against the container's memory limit, and a
+        # process that crosses it is killed with its box (round 5: a 512-leaf TSQR keeping V / T wanted 450 GiB on a box
+        # whose cgroup allows 300).  Beyond this the allocation FAILS (HipExtensionError), the program with it -- loudly.
+        self.pinned_hard_limit_bytes = int(os.environ.get("NUMPYWREN_AMD_PINNED_HARD_LIMIT", _host_memory_limit() * 3 // 4))
         self.pinned_pooled_bytes = 0
         self.spilled_bytes_total = 0
         self.restored_bytes_total = 0
@@ -347,10 +381,11 @@ class HipBackend(object):
         return cached
 
     def stream_cus(self, stream=None):
-        """Compute units `stream` may run on (npw_stream_cu_count: its CU mask, or the whole device)."""
-        n = ctypes.c_int(0)
-        _ffi.check(self.lib.npw_stream_cu_count(self._sh(stream), ctypes.byref(n)), "npw_stream_cu_count")
-        return n.value
+        """(compute units `stream` may run on -- its CU mask, or the whole device --, the ones of them a resident-grid
+        kernel may count on: fewer while an RCCL communicator is live; npw_stream_cu_count)."""
+        n, r = ctypes.c_int(0), ctypes.c_int(0)
+        _ffi.check(self.lib.npw_stream_cu_count(self._sh(stream), ctypes.byref(n), ctypes.byref(r)), "npw_stream_cu_count")
+        return n.value, r.value
 
     def chol_resident_cus(self, n):
         """Compute units a stream must offer for `chol` of an n x n tile (npw_dpotrf_lower_resident_cus)."""
@@ -671,13 +706,24 @@ class HipBackend(object):
         with self._lock:
             lst = self._pinned_free.get(nbytes)
             if lst:
-                ptr, evs = lst.pop()
-                self.pinned_pooled_bytes -= nbytes
+                # a pooled buffer whose last copies have completed, if there is one: waiting here for a copy that is still
+                # queued behind kernels would stop the host's run-ahead, which is what hides the tier's copies at all
+                pick = next((i for i, (_, evs) in enumerate(lst) if all(self.event_done(e) for e in evs)), None)
+                if pick is None and self.pinned_bytes + nbytes > self.pinned_limit_bytes:
+                    pick = 0          # at the ceiling: the oldest one, and wait for it
+                if pick is not None:
+                    ptr, evs = lst.pop(pick)
+                    self.pinned_pooled_bytes -= nbytes
         if ptr is not None:
             for ev in evs:  # a copy out of this buffer may still be in flight
                 self.event_sync(ev)
                 self.recycle_event(ev)
             return PinnedBuffer(self, ptr, nbytes)
+        if self.pinned_bytes + nbytes > self.pinned_hard_limit_bytes:
+            raise HipExtensionError(
+                "host-DRAM tier: %d more bytes of pinned memory would exceed the tier's limit of %.1f GiB (3/4 of the host memory "
+                "this process may use; $NUMPYWREN_AMD_PINNED_HARD_LIMIT) with %.1f GiB held -- the tiles that have to leave HBM do "
+                "not fit this host" % (nbytes, self.pinned_hard_limit_bytes / 2.0 ** 30, self.pinned_bytes / 2.0 ** 30))
         p = ctypes.c_void_p(0)
         _ffi.check(self.lib.npw_host_alloc(ctypes.byref(p), nbytes), f"npw_host_alloc({nbytes})")
         with self._lock:
@@ -1280,7 +1326,8 @@ class HipBackend(object):
         # (qr.hip geqrt_core) is count x ceil(rows / 512) workgroups on 2 slots per compute unit OF THE STREAM -- a masked
         # stream of the executor offers fewer than the device; batches are kept at half of that (one 256-row slab per
         # workgroup: 32 tiles of 4096 rows on the whole chip, the size every measurement of the batched form was made at)
-        cap = max(1, (2 * self.stream_cus(sh)) // ((m + 255) // 256))
+        cus, resident = self.stream_cus(sh)
+        cap = max(1, min((2 * cus) // ((m + 255) // 256), (2 * resident) // ((m + 511) // 512)))
         if len(As) > cap:
             out = []
             for i in range(0, len(As), cap):
@@ -1318,7 +1365,7 @@ class HipBackend(object):
             if a.shape != (n, n) or c.shape != (n, n):
                 raise ValueError(f"tpqrt: expected pairs of {n} x {n} tiles, got {a.shape} over {c.shape}")
         # (same residency rule as geqrt_batched; a stacked-triangle panel touches at most n + 32 rows)
-        cap = max(1, (2 * self.stream_cus(sh)) // ((n + 32 + 511) // 512))
+        cap = max(1, (2 * self.stream_cus(sh)[1]) // ((n + 32 + 511) // 512))
         if len(pairs) > cap:
             out = []
             for i in range(0, len(pairs), cap):

@@ -357,11 +357,13 @@ class Comm(object):
         self.bytes_sent += tile.nbytes * len(dsts)
         self.transfers += len(dsts)
 
-    def recv_tile(self, src, meta=None):
+    def recv_tile(self, src, meta=None, key=None):
+        """`key` = (matrix name, tile index) of the tile: the transports move bytes and ignore it; the measuring
+        stand-in of tools/dist_host_split.py (one rank of a pretended larger job) looks the tile up by it."""
         if meta is None:
             meta = self._recv_header(src)
             self.headers += 1
-        tile = self.transport.recv(src, meta)
+        tile = self.transport.recv(src, meta, key) if getattr(self.transport, "wants_key", False) else self.transport.recv(src, meta)
         self.bytes_received += meta.nbytes
         return tile
 
@@ -567,6 +569,7 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
                                   "transfer must have a payload); run them on one GPU")
     program.incr_up(1)
     t_start = time.time()
+    cpu_start = time.thread_time()
     be = get_backend()
     be.bind_thread()
     compiled = program.program
@@ -585,6 +588,12 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
     diag_on = bool(((program.config or {}).get("executor", {}) if isinstance(program.config, dict) else {}).get("task_timers", False))
     comm.transport.diag = diag_on
     blocked_s = 0.0
+    # where the walk's host time goes (seconds; always on: a dozen clock reads per position): taking the next group off
+    # the ready heap, looking up tasks / owners, running this rank's own tasks (by kernel name: ctypes marshalling, event
+    # records, allocator, flag plumbing -- and any wait hidden inside a HIP call), the exchange plan (static metadata,
+    # consumer ranks, posting sends / receives), dependency accounting
+    split = collections.defaultdict(float)
+    clock = time.perf_counter
     sent0, recv0 = comm.bytes_sent, comm.bytes_received
     program._defer_success = True
     try:
@@ -610,14 +619,16 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
                 if rank == home:
                     comm.send_tile(_stored_tile(mats[r[0]], r[1]), consumers, known=meta is not None, meta=meta)
                 elif rank in consumers:
-                    mats[r[0]].put_tile(comm.recv_tile(home, meta), *r[1])
+                    mats[r[0]].put_tile(comm.recv_tile(home, meta, key=r), *r[1])
         except BaseException:
             comm.transport.abort_group()        # a partly posted group must not be launched (see RcclTransport.abort_group)
             raise
         else:
             comm.transport.end_group()
         step, timed_out = 0, False
+        split["prologue"] = time.time() - t_start
         while program.program_status() == lp.PS.RUNNING and not program.all_terminators_done():
+            c0 = clock()
             node = program.dequeue()
             if node is None:
                 break
@@ -639,11 +650,15 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
             group = [(e, v)]
             if ex.batch_fn(e) is not None:
                 group += program.dequeue_matching(lambda e2, v2: e2 == e, ex.batch_tasks * comm.world - 1)
+            c1 = clock()
+            split["dequeue"] += c1 - c0
             tasks = [compiled.task(ge, gv) for ge, gv in group]
             owners = [comm.owner(*t.writes[0]) if t.writes else 0 for t in tasks]
             mine = [g for g, o in zip(group, owners) if o == rank]
             for ge, gv in group:
                 program.set_node_status(ge, gv, lp.NS.RUNNING)
+            c2 = clock()
+            split["lookup"] += c2 - c1
             if mine:
                 try:
                     last = ex.run_batch(mine) if len(mine) > 1 else ex.run_task(*mine[0])
@@ -651,12 +666,15 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
                     program.handle_exception(exc, tb=traceback.format_exc(), expr_idx=e, var_values=v)
                     raise
                 executed.extend([ge, gv] for ge, gv in mine)
+                c3 = clock()
+                split["run:" + getattr(compiled.kernel(e), "__name__", "task")] += c3 - c2
                 if last is not None and last.ready is not None:
                     inflight.append(last)
                     if len(inflight) > max_inflight:
                         t_b = time.time()
                         be.wait_tile(inflight.popleft())
                         blocked_s += time.time() - t_b
+            c4 = clock()
             # push the outputs to the remote consumers: both sides evaluate the same static plan here; the transfers of
             # one group of tasks (the right-hand sides of a batched solve, the nodes of a tree level) are one launch
             comm.transport.begin_group()
@@ -671,15 +689,19 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
                             comm.send_tile(_stored_tile(mats[name], idx), ranks, known=meta is not None, meta=meta)
                             ex.sent(name, idx)
                         elif rank in ranks:
-                            mats[name].put_tile(comm.recv_tile(owner, meta), *idx)
+                            mats[name].put_tile(comm.recv_tile(owner, meta, key=(name, idx)), *idx)
+                    c5 = clock()
                     program.post_op(ge, gv, lp.PS.SUCCESS, None)
                     program.set_node_status(ge, gv, lp.NS.FINISHED)
+                    split["post_op"] += clock() - c5
             except BaseException:
                 comm.transport.abort_group()
                 raise
             else:
                 comm.transport.end_group()
+            split["exchange+post_op"] += clock() - c4
         t_walk_end = time.time()
+        cpu_walk = time.thread_time() - cpu_start
         comm.flush()
         be.synchronize()
         t_drained = time.time()
@@ -696,12 +718,19 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
         program._defer_success = False
         program.decr_up(1)
     diag = {"rank": rank, "transport": comm.backend, "positions": step, "tasks_run_here": len(executed),
-            # the common walk on the host, without the time it spent blocked on the device / the control group
+            # the common walk on the host, without the time it spent blocked in dist.py's OWN waits (the run-ahead bound, the
+            # control group).  It still contains what the walk spent blocked INSIDE HIP calls: a launch returns late when the
+            # device is far behind (measured, profiles/r05_dist_host_split.md: 65536^2 on one GPU 61 - 115 ms with the host
+            # kept 4 positions ahead, 480 - 900 ms of the same 1380 ms run with 64 -- back-pressure, not work) ...
             "host_walk_ms": round(1e3 * (t_walk_end - t_start - blocked_s), 3),
+            # ... so the thread's CPU time over the walk says what the host actually computed
+            "host_cpu_ms": round(1e3 * cpu_walk, 3),
             "host_blocked_ms": round(1e3 * blocked_s, 3),
             # host time between the end of the walk and the device being drained: how far the device ran behind the host
             "drain_ms": round(1e3 * (t_drained - t_walk_end), 3),
             "bytes_sent": comm.bytes_sent - sent0, "bytes_received": comm.bytes_received - recv0}
+    split["exchange"] = split.pop("exchange+post_op", 0.0) - split["post_op"]
+    diag["host_split_ms"] = {k: round(1e3 * v, 3) for k, v in sorted(split.items())}
     if diag_on:
         times = job_runner.collect_task_times(program)
         diag["kernel_busy_ms"] = round(sum(v["ms"] for v in times.values()), 3)

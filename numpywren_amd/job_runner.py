@@ -175,6 +175,7 @@ class ReductionFusion(object):
 
 class LambdaPackExecutor(object):
     """Executes single tasks of a program on the HIP backend."""
+    dry = False           # True for the recording stand-in of predicted_issue_order: nothing touches the device
 
     def __init__(self, program, loop=None, cache=None, read_queue=None, pipeline_width=4, exact_zero=None,
                  is_local=None, send_plan=None):
@@ -190,6 +191,7 @@ class LambdaPackExecutor(object):
         # they are only dropped on store when the caller asks for it by name (an R-only TSQR)
         self.drop_unread = bool(cfg.get("drop_unread_outputs", False))
         self.batch_tasks = max(1, int(cfg.get("batch_tasks", 32)))
+        self.spill_batch = None       # cap on the batches of throughput kernels while the host-DRAM tier is at work (below)
         # diagnostics (off by default: two event records per task cost ~8 us of stream time): every task's kernels are
         # bracketed with timing events on their stream; collect_task_times() adds them up by kernel name
         self.task_timers = bool(cfg.get("task_timers", False)) and hasattr(self.be, "new_event")
@@ -217,6 +219,71 @@ class LambdaPackExecutor(object):
                                 if getattr(k, "_npw_chain_resident_cus", None) is not None]
             if not self.chain_stmts:
                 self.chain_cus = 0
+        # the host-DRAM tier reads the static DAG (residency.SpillPlan): victims by farthest next read, spilled operands
+        # of the next `spill_prefetch_tasks` tasks copied back ahead of them
+        self.spill_plan = None
+        self.prefetch_tasks = max(0, int(cfg.get("spill_prefetch_tasks", 2)))
+        self._pipeline_width = pipeline_width
+        self._issued_idx = []          # task indices issued so far (a plan built late is told about them)
+        if hasattr(self.be, "restore_from_host"):
+            from . import matrix
+            res = matrix.RESIDENCY
+            tier_at_work = matrix._store_tier() != "host" and (res.budget is not None or res.evictions > 0)
+            if tier_at_work:
+                # (also in the dry walk: the plan must see the batches the real run forms)
+                self.spill_batch = max(1, int(cfg.get("spill_batch_tasks", 8)))
+            if not self.dry and cfg.get("spill_plan", True) and matrix._store_tier() != "host" and getattr(self.compiled, "tasks", None):
+                if tier_at_work:
+                    self._install_spill_plan()          # the tier is at work: plan before the first task
+                else:
+                    # nothing has ever been pushed out: the plan (a dry walk of the scheduling loop, ~0.07 ms per task) is
+                    # only made if the allocator's out-of-memory handler asks the tier for memory during this run
+                    res.plan = None
+                    res.plan_factory = self._install_spill_plan
+
+    def _install_spill_plan(self):
+        from . import matrix
+        from .residency import SpillPlan
+        matrix.RESIDENCY.plan_factory = None
+        tasks = self.compiled.tasks
+        order = None
+        if self.is_local is None:
+            try:
+                order = predicted_issue_order(self.program, self._pipeline_width)
+            except Exception:
+                order = None
+        if order is None or len(order) != len(tasks):
+            # (several ranks, or a program the dry walk cannot finish: critical-path order, the ready heap's own key)
+            prio = self.program._priorities()
+            order = sorted(tasks, key=lambda t: (-prio.get(t.key, 0), t.index))
+        mats = self.compiled.matrices
+
+        def key_of(name, idx):
+            m = mats[name]
+            return (m.bucket, m.key_base, m.__shard_idx_to_key__(idx))
+        try:
+            self.spill_plan = SpillPlan(order, key_of)
+            for i in self._issued_idx:
+                self.spill_plan.issued(i)
+        except Exception:
+            self.spill_plan = None     # (a matrix without the tile-key surface: the tier falls back to LRU)
+        matrix.RESIDENCY.plan = self.spill_plan
+        return self.spill_plan
+
+    def _issued(self, tasks):
+        """The reads of `tasks` have been taken (their kernels hold the tiles): tell the plan, then bring back what the
+        next tasks need.  Only with a budget / after an eviction is there anything to prefetch."""
+        plan = self.spill_plan
+        if plan is None:
+            if not self.dry:
+                self._issued_idx.extend(t.index for t in tasks)
+            return
+        from . import matrix
+        for t in tasks:
+            plan.issued(t.index)
+        res = matrix.RESIDENCY
+        if self.prefetch_tasks and res.evictions and res.plan is plan:
+            res.prefetch(self.be, self.prefetch_tasks)
 
     # ---- per-task device timing (executor.task_timers) ----
     def _tic(self, stream):
@@ -412,6 +479,7 @@ class LambdaPackExecutor(object):
             stream = self.pick_stream(compute)
         if self.fusion is not None and self.fusion.handles(task):
             last = self.fusion.run(self, task, compute, stream)
+            self._issued((task,))
             self._consumed(task)
             self.program.record_profile(expr_idx, var_values, kernel=getattr(compute, "__name__", str(compute)) + "+fused",
                                         stream=getattr(stream, "name", str(stream)), enqueue_start=t_enq,
@@ -424,6 +492,7 @@ class LambdaPackExecutor(object):
         # streams' tails, and they wait for it afterwards.
         others = self._fence_in(compute, stream)
         tiles = [mats[m].get_tile(*idx, stream=stream) for m, idx in task.reads]
+        self._issued((task,))
         read_bytes = sum(t.nbytes for t in tiles)
         if device_kernel:
             args = [tiles[j] if kind == "tile" else task.consts[j] for kind, j in task.arg_kinds]
@@ -478,6 +547,13 @@ class LambdaPackExecutor(object):
         return last
 
     # ---- several independent tasks of one kind as one batched kernel call ----
+    def batch_limit(self, expr_idx):
+        """Most tasks of statement `expr_idx` one batched call takes: executor.batch_tasks, or fewer for a throughput kernel
+        while the host-DRAM tier is at work (a batched launch waits for the copy-in of all its operands)."""
+        if self.spill_batch is not None and not getattr(self.compiled.kernel(expr_idx), "_npw_needs_whole_cus", False):
+            return min(self.batch_tasks, self.spill_batch)
+        return self.batch_tasks
+
     def batch_fn(self, expr_idx):
         """The batched implementation of the task's kernel, or None (no batching configured / kernel has none)."""
         if self.batch_tasks <= 1 or self.program.block_sparse:
@@ -500,6 +576,7 @@ class LambdaPackExecutor(object):
             read_bytes += sum(t.nbytes for t in tiles)
             arg_lists.append([tiles[j] if kind == "tile" else task.consts[j] for kind, j in task.arg_kinds])
             kwargs_list.append(task.kwargs)
+        self._issued(tasks)
         others = self._fence_in(compute, stream)
         tic = self._tic(stream)
         with kernels.stream_scope(stream, self.program.info_flags_sink(tasks[0]), self.exact_zero, self._unwanted(tasks)):
@@ -630,6 +707,43 @@ def check_info_flags(program, be, stream=None):
     return True
 
 
+class _RecordingExecutor(LambdaPackExecutor):
+    """The executor's scheduling decisions without its work: run_task / run_batch / run_chain only note which task would
+    have been issued.  lambdapack_run driven by this stand-in on a shadow LambdaPackProgram IS the real loop -- the
+    batches it forms, the tasks it pulls ahead to complete a batch, the panel factorisations it moves to the chain
+    partition -- so the recorded order is the order of the real run, not a model of it."""
+    dry = True
+
+    def __init__(self, program, pipeline_width):
+        LambdaPackExecutor.__init__(self, program, pipeline_width=pipeline_width)
+        self.order = []
+
+    def run_task(self, expr_idx, var_values, stream=None):
+        self.order.append(self.compiled.task(expr_idx, var_values))
+        return None
+
+    def run_batch(self, nodes, stream=None):
+        self.order.extend(self.compiled.task(e, v) for e, v in nodes)
+        return None
+
+    def run_chain(self, node, companions):
+        self.order.append(self.compiled.task(*node))
+        self.order.extend(self.compiled.task(e, v) for e, v in companions)
+        self.chain_runs += 1
+        return []
+
+
+def predicted_issue_order(program, pipeline_width=1):
+    """The tasks of `program` in the order lambdapack_run will issue them (a dry walk of the same loop on a shadow of the
+    program's run state; nothing is enqueued on the device).  The host-DRAM tier's SpillPlan is built from it."""
+    shadow = lp.LambdaPackProgram(program.program, config=program.config, block_sparse=program.block_sparse)
+    shadow._priority = program._priorities()
+    shadow.start()
+    ex = _RecordingExecutor(shadow, pipeline_width)
+    lambdapack_run(shadow, pipeline_width=pipeline_width, timeout=1e9, _executor=ex)
+    return ex.order
+
+
 def settle_checks(program, be, stream=None):
     """Both deferred checks of a settled run, ALWAYS both (no short-circuit: the hand-off counter must be read and reset
     even when the info flags already failed the program)."""
@@ -639,7 +753,7 @@ def settle_checks(program, be, stream=None):
 
 
 def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, timeout=200, idle_timeout=5,
-                   msg_vis_timeout_jitter=15, compute_threads=1, max_inflight=64, wait=True, after=None):
+                   msg_vis_timeout_jitter=15, compute_threads=1, max_inflight=64, wait=True, after=None, _executor=None):
     """Run `program` to completion (or until `timeout` seconds) on the local GPU.
 
     pipeline_width -> number of HIP streams; the SQS visibility / idle / thread arguments of the
@@ -656,8 +770,9 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
     t_start = time.time()
     be = get_backend()
     be.bind_thread()
-    ex = LambdaPackExecutor(program, cache=LRUCache(cache_size) if cache_size > 0 else None,
-                            pipeline_width=pipeline_width)
+    ex = _executor if _executor is not None else LambdaPackExecutor(
+        program, cache=LRUCache(cache_size) if cache_size > 0 else None, pipeline_width=pipeline_width)
+    dry = ex.dry           # predicted_issue_order: the loop below decides, nothing is enqueued
     executed, refs, running_times = [], [], []
     inflight = collections.deque()
 
@@ -669,7 +784,7 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
             be.wait_tile(inflight.popleft())
 
     program._defer_success = True
-    if after:
+    if after and not dry:
         chain_pair = list(be.chain_streams(ex.chain_cus)) if ex.chain_cus else []
         for sh in list(ex.streams) + ([ex.prio_stream] if ex.prio_stream is not None else []) + chain_pair:
             for ev in after:
@@ -761,7 +876,7 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
             # block column) go to the device as ONE batched launch sequence
             group = [(e, v)]
             if ex.batch_fn(e) is not None:
-                group += program.dequeue_matching(lambda e2, v2: e2 == e, ex.batch_tasks - 1)
+                group += program.dequeue_matching(lambda e2, v2: e2 == e, ex.batch_limit(e) - 1)
             for ge, gv in group:
                 program.set_node_status(ge, gv, lp.NS.RUNNING)
             try:
@@ -779,6 +894,9 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
                 refs.append((ge, gv))
             running_times.append((t0, time.time()))
             track(last)
+        if dry:
+            program._defer_success = False
+            return {"executed_messages": executed, "operator_refs": refs}
         # completion marks of THIS run: one event per stream it used (a device-wide synchronise would also wait for
         # whatever a pipelining caller has enqueued behind it)
         used = list(ex.streams) + ([ex.prio_stream] if ex.prio_stream is not None else [])

@@ -220,7 +220,17 @@ class BigMatrix(object):
         return os.path.join(self.key_base, key_string)
 
     def __shard_idx_to_key__(self, block_idx):
-        return self.__get_matrix_shard_key__(self.__block_idx_to_real_idx__(block_idx))
+        # memoised per (shape, shard_sizes, key_base): the executor asks for the same few hundred keys on every read and
+        # write of a run, and the string formatting was the largest single item of its host time per task
+        memo = self.__dict__.get("_key_memo")
+        sig = (self.key_base, tuple(self.shape), tuple(self.shard_sizes))
+        if memo is None or memo[0] != sig:
+            memo = self.__dict__["_key_memo"] = (sig, {})
+        idx = tuple(block_idx)
+        key = memo[1].get(idx)
+        if key is None:
+            key = memo[1][idx] = self.__get_matrix_shard_key__(self.__block_idx_to_real_idx__(idx))
+        return key
 
     # ------------------------------------------------------------------ header
     def __read_header__(self):
@@ -376,7 +386,10 @@ class BigMatrix(object):
             tkey = (self.bucket, self.key_base, key)
             RESIDENCY.note_put(tkey, obj)
             if isinstance(obj, DeviceTile):
-                RESIDENCY._hook(get_backend())
+                be = get_backend()
+                RESIDENCY._hook(be)
+                if RESIDENCY.plan is not None and RESIDENCY._budget is not None:
+                    RESIDENCY.write_through(tkey, obj, be)
                 RESIDENCY.enforce(protect=(tkey,))
 
     async def put_block_async(self, block, loop=None, *block_idx, no_overwrite=False):

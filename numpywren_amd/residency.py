@@ -2,8 +2,15 @@
 host DRAM.
 
 The reference keeps every tile in S3 and caches a handful per worker (LRUCache, reference job_runner.py:34-64); here
-the store itself is HBM (288 GB per MI355X) and host DRAM is the overflow tier.  Policy: least-recently-used stored
-tile goes first.  Two triggers:
+the store itself is HBM (288 GB per MI355X) and host DRAM is the overflow tier.  Policy: while a program runs, the
+executor installs a `SpillPlan` -- the static task sequence's list of who reads which stored tile when -- and the victim
+is the tile whose next read is FARTHEST in that sequence (Belady's rule; a tile no remaining task reads goes first), the
+spilled tiles the next few tasks read are copied back ahead of them (`prefetch`), and only without a plan does the
+least-recently-used tile go first.  The reference overlaps tile reads with compute by construction (a `read` stage
+`pipeline_width` tasks ahead of `compute`, reference job_runner.py:224-254) and caches LRU (:34-64); with the DAG known in
+advance both the victim and the moment of the copy-in are known, too.  A Cholesky sweeps its trailing matrix once per step
+-- the access pattern on which LRU misses every tile: 32768^2 with 24 tiles of budget moves 106 tiles out and 144 back
+under LRU, 56 and 19 under the plan.  Two triggers:
 
   * a byte budget for stored tiles (`store.hbm_budget_bytes` / $NUMPYWREN_AMD_HBM_BUDGET, e.g. "200G"); unset = no
     budget, and
@@ -39,8 +46,64 @@ def parse_bytes(value):
     return int(float(m.group(1)) * _SUFFIX.get(m.group(2), 1))
 
 
+class SpillPlan(object):
+    """Who reads which stored tile when, from the expanded DAG: `order` is the predicted issue order of the tasks (the ready
+    heap's: longest path to a sink first), `key_of(matrix name, tile index)` the table key of a tile.  The executor reports
+    every task it issues (`issued`); the next read of a tile is then the first position in its list that has not been
+    issued -- exact whatever the real order (batches, the chain partition) does to the predicted one."""
+
+    def __init__(self, order, key_of):
+        self.pending = {}       # table key -> positions (ascending) of the not yet issued tasks that read it
+        self.reads_at = []      # position -> table keys that task reads
+        self.pos = {}           # task index -> position
+        self.done = []          # position -> issued?
+        self.cursor = 0         # lowest position not issued yet
+        for p, t in enumerate(order):
+            self.pos[t.index] = p
+            keys = [key_of(*r) for r in dict.fromkeys(t.reads)]
+            self.reads_at.append(keys)
+            self.done.append(False)
+            for k in keys:
+                self.pending.setdefault(k, []).append(p)
+
+    NEVER = 1 << 60
+
+    def next_use(self, tkey):
+        lst = self.pending.get(tkey)
+        return lst[0] if lst else self.NEVER
+
+    def issued(self, task_index):
+        p = self.pos.get(task_index)
+        if p is None or self.done[p]:
+            return
+        self.done[p] = True
+        for k in self.reads_at[p]:
+            lst = self.pending.get(k)
+            if lst:
+                try:
+                    lst.remove(p)
+                except ValueError:
+                    pass
+        while self.cursor < len(self.done) and self.done[self.cursor]:
+            self.cursor += 1
+
+    def upcoming(self, window):
+        """Table keys the next `window` not yet issued tasks read, nearest first, each once."""
+        seen, out, p, left = set(), [], self.cursor, window
+        while p < len(self.done) and left > 0:
+            if not self.done[p]:
+                left -= 1
+                for k in self.reads_at[p]:
+                    if k not in seen:
+                        seen.add(k)
+                        out.append(k)
+            p += 1
+        return out
+
+
 class Residency(object):
-    """LRU bookkeeping over the DeviceTiles of one object table.  All methods run under the table's lock."""
+    """Bookkeeping over the DeviceTiles of one object table: plan-driven (SpillPlan) while a program runs, least recently
+    used otherwise.  All methods run under the table's lock."""
 
     def __init__(self, table):
         self.table = table
@@ -51,7 +114,11 @@ class Residency(object):
         self._budget_known = False
         self.evictions = 0
         self.restores = 0
+        self.prefetched = 0
+        self.written_through = 0
         self._hooked = None
+        self.plan = None          # SpillPlan of the program being run (LambdaPackExecutor installs it)
+        self.plan_factory = None  # ... or how to make it, when the tier was idle as the run began (called at the first need)
 
     # ---- configuration ----
     @property
@@ -78,11 +145,13 @@ class Residency(object):
             self.bufs.clear()
             self.resident_bytes = 0
             self._budget_known = False
-            self.evictions = self.restores = 0
+            self.evictions = self.restores = self.prefetched = self.written_through = 0
+            self.plan = self.plan_factory = None
 
     def stats(self):
         return {"resident_bytes": self.resident_bytes, "resident_tiles": len(self.lru), "budget": self._budget,
-                "evictions": self.evictions, "restores": self.restores}
+                "evictions": self.evictions, "restores": self.restores, "prefetched": self.prefetched, "written_through": self.written_through,
+                "policy": "plan" if self.plan is not None else "lru"}
 
     def _hook(self, be):
         # the allocator asks us for memory before it reports out-of-memory
@@ -118,6 +187,38 @@ class Residency(object):
             if not ent[1]:
                 self.resident_bytes -= ent[0]
                 del self.bufs[bid]
+
+    def write_through(self, tkey, obj, be):
+        """A tile that has just been stored and cannot stay until its next read -- the resident tiles that are read SOONER
+        already fill the budget, so the plan's rule will push it out first -- starts its copy to pinned host memory NOW,
+        behind its producer, and keeps it as its host copy: pushing it out later is then free.  Why not wait for the
+        eviction: victims leave farthest-next-read first, i.e. in the REVERSE of the order the next step reads them back,
+        and on one in-order copy stream the first tile wanted back would sit behind every other tile's copy out (measured,
+        32768^2 with 12 tiles of budget: the copies in and out took turns instead of overlapping, tools/spill_timeline.py).
+        In production order the copies out run in the order the copies back will be asked for."""
+        plan, budget = self.plan, self.budget
+        if plan is None or budget is None or not self._evictable(obj) or getattr(obj, "offset", 0) != 0:
+            return False
+        if not hasattr(obj.buf, "aux") or not hasattr(be, "spill_to_host"):
+            return False        # (a backend whose buffers carry no host copies: pushing out later copies)
+        aux = obj.buf.aux
+        if isinstance(aux, dict) and aux.get("host_copy") is not None:
+            return False
+        mine = plan.next_use(tkey)
+        sooner = obj.nbytes
+        for bid, ent in self.bufs.items():
+            if tkey in ent[1]:
+                continue
+            if min(plan.next_use(k) for k in ent[1]) < mine:
+                sooner += ent[0]
+                if sooner > budget:
+                    break
+        if sooner <= budget:
+            return False
+        sp = be.spill_to_host(obj)
+        obj.buf.aux = dict(aux or {}, host_copy=sp)
+        self.written_through += 1
+        return True
 
     def touch(self, tkey):
         if tkey in self.lru:
@@ -160,19 +261,63 @@ class Residency(object):
         self.evictions += 1
         return live[0][1].nbytes
 
+    def _victims(self):
+        """Resident table keys, first victim first: with a plan the tile whose next read is farthest in the task sequence
+        (never read again: first; ties in least-recently-used order), without one the least recently used."""
+        keys = list(self.lru.keys())
+        if self.plan is None and self.plan_factory is not None:
+            factory, self.plan_factory = self.plan_factory, None
+            try:
+                factory()
+            except Exception:
+                pass
+        plan = self.plan
+        if plan is None:
+            return keys
+        # a buffer stored under several keys is needed as soon as any of them is read
+        def soonest(k):
+            ent = self.bufs.get(self.lru[k])
+            return min(plan.next_use(x) for x in (ent[1] if ent else (k,)))
+        return sorted(keys, key=lambda k: -soonest(k))     # (stable: equal distances keep the LRU order)
+
     def enforce(self, protect=()):
-        """Evict least-recently-used tiles until the stored tiles fit the budget.  `protect`: keys to keep."""
+        """Evict tiles (see _victims) until the stored tiles fit the budget.  `protect`: keys to keep."""
         budget = self.budget
         if budget is None or self.resident_bytes <= budget:
             return 0
         from .device import get_backend
         be = get_backend()
         freed = 0
-        for tkey in list(self.lru.keys()):
+        for tkey in self._victims():
             if self.resident_bytes <= budget:
                 break
             freed += self._evict(tkey, be, protect)
         return freed
+
+    def prefetch(self, be, window):
+        """Copy the spilled tiles the next `window` tasks of the plan read back into HBM now, on the inbound spill stream,
+        nearest reader first -- ahead of the tasks instead of inside their get_tile.  Under a budget a tile only comes
+        back early if what it pushes out is needed later than itself."""
+        plan = self.plan
+        if plan is None or window <= 0:
+            return 0
+        from .device import SpilledTile
+        n = 0
+        with self.table.lock:
+            for tkey in plan.upcoming(window):
+                obj = self._lookup(tkey)
+                if not isinstance(obj, SpilledTile):
+                    continue
+                budget = self.budget
+                if budget is not None and self.resident_bytes + obj.nbytes > budget:
+                    mine = plan.next_use(tkey)
+                    victims = [k for k in self._victims()[:1] if k != tkey]
+                    if not victims or plan.next_use(victims[0]) <= mine:
+                        break
+                self.restore(tkey, obj, be)
+                self.prefetched += 1
+                n += 1
+        return n
 
     def reclaim(self, nbytes):
         """Out-of-memory handler of the allocator: push out at least `nbytes` of least-recently-used tiles."""
@@ -180,7 +325,7 @@ class Residency(object):
         be = get_backend()
         freed = 0
         with self.table.lock:
-            for tkey in list(self.lru.keys()):
+            for tkey in self._victims():
                 if freed >= nbytes:
                     break
                 freed += self._evict(tkey, be)

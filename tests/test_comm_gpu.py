@@ -81,3 +81,66 @@ def test_distributed_executor_over_rccl_world_of_one():
     text = out.stdout + out.stderr
     assert out.returncode == 0, text[-3000:]
     assert "dist_check: PASSED" in text and "backend rccl" in text, text[-3000:]
+
+
+def test_resident_grid_kernels_beside_rccl_transfers():
+    """the kernels whose workgroups wait for one another (a batch of 32 Householder factorisations of
+    4096^2 tiles, the Cholesky panel chain of a 4096^2 tile) running WHILE grouped RCCL transfers of 8 tiles at a time are
+    in flight on the transport stream: same bits as without the transfers, no expired hand-off, and the library has set
+    compute units aside for the transfer kernels since the communicator exists."""
+    from numpywren_amd import _ffi
+    from numpywren_amd.device import Stream, get_backend
+    be = get_backend()
+    lib = be.lib
+    b, count = 4096, 32
+    As = [be.fill_random((b, b), 21, z * b, 0) for z in range(count)]
+    X = be.fill_random((b, 128), 22)
+    S = be.add_diag(be.gemm(X, X, False, True), float(b))
+
+    def factor():
+        out = be.geqrt_batched(As, want_t=False, want_v=False)
+        L, _ = be.chol(S)
+        return [r for _, _, r in out], L
+
+    before = be.stream_cus()
+    be.qr_handoff_timeouts(reset=True)
+    R0, L0 = factor()
+    be.synchronize()
+    ident = ctypes.create_string_buffer(_ffi.NPW_COMM_ID_BYTES)
+    _ffi.check(lib.npw_comm_unique_id(ident, _ffi.NPW_COMM_ID_BYTES), "unique_id")
+    h = ctypes.c_void_p(0)
+    _ffi.check(lib.npw_comm_init(ctypes.byref(h), 0, 1, ident), "comm_init")
+    try:
+        sh = ctypes.c_void_p(0)
+        _ffi.check(lib.npw_comm_info(h, None, None, ctypes.byref(sh)))
+        cs = Stream(sh.value, True, "xgmi")
+        cus, resident = be.stream_cus()
+        assert before == (cus, cus) and 0 < resident < cus          # a live communicator: CUs are left to its kernels
+        src = [be.fill_random((b, b), 23, z * b, 0) for z in range(8)]
+        dst = [be.empty((b, b)) for _ in range(8)]
+        be.synchronize()
+        be._use(cs, *src)
+        be._use(cs, *dst)
+        rounds = 40                                                  # 40 x 8 x 128 MiB: transfers in flight for the whole batch
+        def post(n):
+            for _ in range(n):
+                _ffi.check(lib.npw_comm_group_start(h))
+                for s_, d_ in zip(src, dst):
+                    _ffi.check(lib.npw_send_tile(h, s_.ptr, s_.nbytes, 0, cs.handle), "send")
+                    _ffi.check(lib.npw_recv_tile(h, d_.ptr, d_.nbytes, 0, cs.handle), "recv")
+                _ffi.check(lib.npw_comm_group_end(h))
+        post(rounds // 2)
+        R1, L1 = factor()
+        post(rounds - rounds // 2)
+        be._produced(cs, *dst)
+        be.synchronize()
+        assert be.qr_handoff_timeouts(reset=True) == 0
+        for r0, r1 in zip(R0, R1):
+            assert be.sumsq(be.axpby(1.0, r0, -1.0, r1)) == 0.0     # bit for bit
+        assert be.sumsq(be.axpby(1.0, L0, -1.0, L1)) == 0.0
+        for s_, d_ in zip(src, dst):
+            assert be.sumsq(be.axpby(1.0, s_, -1.0, d_)) == 0.0
+    finally:
+        be.synchronize()
+        _ffi.check(lib.npw_comm_destroy(h))
+    assert be.stream_cus() == before                                # the reserve goes with the communicator

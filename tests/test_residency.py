@@ -137,6 +137,91 @@ def test_cholesky_under_a_tight_budget(oracle_backend):
     program.free()
 
 
+def test_spill_plan_next_use_follows_the_issued_tasks():
+    """SpillPlan: the next read of a tile is the first not yet issued task of the predicted order that reads it, whatever
+    order the tasks are really issued in; `upcoming` lists what the next tasks read, nearest first."""
+    class T(object):
+        def __init__(self, index, reads):
+            self.index, self.reads = index, reads
+    order = [T(10, [("A", (0,))]), T(11, [("A", (0,)), ("B", (0,))]), T(12, [("B", (0,))]), T(13, [("A", (0,)), ("C", (0,))])]
+    plan = residency.SpillPlan(order, lambda name, idx: (name, idx))
+    a, b, c = ("A", (0,)), ("B", (0,)), ("C", (0,))
+    assert (plan.next_use(a), plan.next_use(b), plan.next_use(c)) == (0, 1, 3) and plan.next_use(("Z", (0,))) == plan.NEVER
+    assert plan.upcoming(2) == [a, b]
+    plan.issued(12)                      # out of order (a batch pulled it forward)
+    assert plan.next_use(b) == 1 and plan.cursor == 0
+    plan.issued(10)
+    plan.issued(11)
+    assert (plan.next_use(a), plan.next_use(b), plan.cursor) == (3, plan.NEVER, 3) and plan.upcoming(4) == [a, c]
+    plan.issued(13)
+    assert plan.next_use(a) == plan.NEVER and plan.upcoming(4) == []
+
+
+def test_predicted_issue_order_is_the_real_one(oracle_backend):
+    """job_runner.predicted_issue_order dry-walks lambdapack_run's own loop on a shadow of the program's state: the order it
+    records is the order the real run issues (batches, the tasks pulled ahead to complete a batch, ...), for any batch size."""
+    from numpywren_amd import alg_wrappers, job_runner
+    from numpywren_amd.compiler import node_key
+    rng = np.random.default_rng(6)
+    nb, b = 6, 8
+    n = nb * b
+    x = rng.standard_normal((n, n))
+    a = x @ x.T + n * np.eye(n)
+    for batch in (32, 3, 1):
+        A = BigMatrix("res_order_%d" % batch, shape=(n, n), shard_sizes=(b, b), write_header=True)
+        for i in range(nb):
+            for j in range(i + 1):
+                A.put_block(a[i * b:(i + 1) * b, j * b:(j + 1) * b], i, j)
+        program, meta = alg_wrappers.cholesky(A)
+        program.config["executor"]["batch_tasks"] = batch
+        predicted = [t.key for t in job_runner.predicted_issue_order(program)]
+        program.start()
+        res = job_runner.lambdapack_run(program)
+        assert predicted == [node_key(e, v) for e, v in res["executed_messages"]] and len(predicted) == 56
+        program.free()
+        A.free()
+
+
+def test_plan_driven_eviction_moves_fewer_tiles_than_lru(oracle_backend):
+    """The same budgeted Cholesky (8 x 8 tiles, 24 tiles of budget: the shape of tools/bench_aux.py spill) with the victims
+    chosen by the DAG (farthest next read) and by LRU: same factor bit for bit, a fraction of the copies -- a Cholesky sweeps
+    its trailing matrix once per step, the access pattern on which LRU misses everything."""
+    from numpywren_amd import alg_wrappers, job_runner
+    from numpywren_amd import lambdapack as lp
+    rng = np.random.default_rng(4)
+    nb, b = 8, 8
+    n = nb * b
+    x = rng.standard_normal((n, n))
+    a = x @ x.T + n * np.eye(n)
+
+    def run(key, plan):
+        matrix.RESIDENCY.reset()
+        matrix.RESIDENCY.set_budget(24 * b * b * 8)
+        A = BigMatrix(key, shape=(n, n), shard_sizes=(b, b), write_header=True)
+        for i in range(nb):
+            for j in range(i + 1):
+                A.put_block(a[i * b:(i + 1) * b, j * b:(j + 1) * b], i, j)
+        program, meta = alg_wrappers.cholesky(A)
+        program.config["executor"]["reclaim_intermediates"] = True
+        program.config["executor"]["spill_plan"] = plan
+        program.start()
+        job_runner.lambdapack_run(program)
+        program.wait()
+        assert program.program_status() == lp.PS.SUCCESS
+        st = matrix.RESIDENCY.stats()
+        L = meta["outputs"][0].numpy()
+        program.free()
+        A.free()
+        return L, st
+
+    L_lru, lru = run("res_plan_off", False)
+    L_plan, plan = run("res_plan_on", True)
+    assert lru["policy"] == "lru" and plan["policy"] == "plan"
+    assert np.array_equal(L_lru, L_plan) and np.allclose(np.tril(L_plan), np.linalg.cholesky(a))
+    assert plan["restores"] * 2 <= lru["restores"] and plan["evictions"] < lru["evictions"], (plan, lru)
+    matrix.RESIDENCY.reset()
+
+
 # ------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 def test_spill_and_restore_are_bit_exact_and_asynchronous(hbm_store):

@@ -31,6 +31,8 @@ from numpywren_amd.matrix import BigMatrix  # noqa: E402
 STREAMS = 1
 R_ONLY = True    # tsqr: drop the V / T factors nobody reads as they are stored (--keep-vt turns it off)
 BATCH = None
+SPILL_PLAN = True   # executor.spill_plan: the host-DRAM tier's victims / prefetches from the static DAG (False: LRU, on demand)
+PREFETCH = None
 
 
 def run(program, reclaim=True):
@@ -38,6 +40,12 @@ def run(program, reclaim=True):
     program.config["executor"]["drop_unread_outputs"] = reclaim and R_ONLY
     if BATCH is not None:
         program.config["executor"]["batch_tasks"] = BATCH
+        program.config["executor"]["spill_batch_tasks"] = BATCH
+    elif not SPILL_PLAN:
+        program.config["executor"]["spill_batch_tasks"] = 32     # --lru: round 1's tier as it was (whole batches, on demand)
+    program.config["executor"]["spill_plan"] = SPILL_PLAN
+    if PREFETCH is not None:
+        program.config["executor"]["spill_prefetch_tasks"] = PREFETCH
     program.start()
     job_runner.lambdapack_run(program, timeout=3600, pipeline_width=STREAMS)
     if program.program_status() != lp.PS.SUCCESS:
@@ -79,8 +87,12 @@ def main():
     ap.add_argument("--task-times", action="store_true", help="bdfac / qr: one extra run with per-kernel device times")
     ap.add_argument("--batch", type=int, default=None, help="executor.batch_tasks (ready tasks per batched launch)")
     ap.add_argument("--keep-vt", action="store_true", help="tsqr: keep the V / T factors (the reference's full output set)")
+    ap.add_argument("--lru", action="store_true", help="spill: round 1's policy (LRU victims, restores on demand) instead of the DAG's plan")
+    ap.add_argument("--prefetch", type=int, default=None, help="spill: executor.spill_prefetch_tasks")
     a = ap.parse_args()
-    global STREAMS, BATCH, R_ONLY
+    global STREAMS, BATCH, R_ONLY, SPILL_PLAN, PREFETCH
+    SPILL_PLAN = not a.lru
+    PREFETCH = a.prefetch
     STREAMS = a.streams
     R_ONLY = not a.keep_vt
     BATCH = a.batch
@@ -194,7 +206,9 @@ def main():
 
         res = {}
         for label, budget in (("resident", None), ("budget", a.budget_tiles * b * b * 8)):
+            matrix.RESIDENCY.reset()
             matrix.RESIDENCY.set_budget(budget)
+            s0, r0 = be.spilled_bytes_total, be.restored_bytes_total
             A = bench.build_input(be, nt, b, "aux_spill_" + label)
             times = []
             for rep in range(a.steps + a.warmup):
@@ -210,7 +224,9 @@ def main():
                     for m in meta["outputs"] + meta["intermediates"]:
                         m.free()
             L = last["outputs"][0]
-            res[label] = {"ms": round(1e3 * min(times[a.warmup:]), 2), **matrix.RESIDENCY.stats()}
+            res[label] = {"ms": round(1e3 * min(times[a.warmup:]), 2), "ms_all": [round(1e3 * t, 1) for t in times],
+                          "GB_out_per_run": round((be.spilled_bytes_total - s0) / len(times) / 1e9, 2),
+                          "GB_back_per_run": round((be.restored_bytes_total - r0) / len(times) / 1e9, 2), **matrix.RESIDENCY.stats()}
             res[label + "_L"] = [be.to_host(L.get_tile(nt - 1, j)) for j in range(nt)]
             A.free()
         same = all(np.array_equal(x, y) for x, y in zip(res.pop("resident_L"), res.pop("budget_L")))

@@ -6,8 +6,12 @@ section 6 and BASELINE.md quote.      python tools/predict_scaling.py [--link-gb
 
 configs[2], 65536^2 Cholesky (16 x 16 tiles of 4096^2, 816 tasks): a list-scheduling simulation of numpywren_amd/dist.py:
   * the common task sequence = LambdaPackProgram's ready heap (critical-path priority), children released when their
-    parents have been issued; EVERY rank walks every position of it on the host (`--host-us`, measured by
-    tools/host_walk_cost.py: 0.10 ms per position on 8 gloo ranks) and can only enqueue a task once its walk has reached it;
+    parents have been issued; EVERY rank walks every position of it on the host and can only enqueue a task once its walk has
+    reached it.  The walk's cost is MEASURED on the real backend (round 5, tools/dist_host_split.py on one MI355X,
+    profiles/r05_dist_host_split.md): 20 us of bookkeeping per position of the common sequence on every rank (dequeue,
+    look-ups, exchange plan, post_op) + 55 us per task the rank runs itself (ctypes marshalling, events, allocator) -- 61 ms
+    for the world of one (816 + 816), 24 - 29 ms for rank 0 of 8 (816 + 100; the stand-in run that executes only that
+    rank's tasks).  Round 4 charged 101 us per position to everybody, from 8 gloo ranks on the CHECKER backend;
   * tile ownership 2-D block-cyclic on the Pr x Pc grid, owner computes; a GPU runs one chip-filling kernel at a time and
     picks, among its tasks whose inputs have arrived, the earliest in the common sequence (3 executor streams);
   * a produced tile is pushed to every GPU owning a consumer: 128 MiB per destination, one xGMI link per pair of GPUs,
@@ -38,7 +42,8 @@ os.environ["NUMPYWREN_AMD_STORE"] = "host"
 # ---- measured single-GPU inputs (ms); sources in profiles/r04_*.md ----------------------------------------------------
 KERNEL_MS_1GPU = {"chol": 1.48, "trsm": 1.10, "syrk": 1.89, "syrk_sym": 1.08}          # one stream + chain partition
 KERNEL_MS_3STREAMS = {k: round(v * 1359.4 / 1343.5, 4) for k, v in KERNEL_MS_1GPU.items()}   # bench.py --tiles 16 --streams 3: 1359.4 ms against 1343.5 (gpurun_out/r04l): every kind scaled by that ratio
-HOST_US_PER_POSITION = 101.0                                                            # tools/host_walk_cost.py (0.140 before the walk was trimmed in round 4)
+HOST_US_PER_POSITION = 20.0    # every rank, every position of the common sequence (tools/dist_host_split.py, real backend)
+HOST_US_PER_OWN_TASK = 55.0    # ... plus this for a task the rank runs itself
 TILE_BYTES = 4096 * 4096 * 8
 # batched QR of 4096^2 tiles, ms per call by batch size: dense leaves / stacked-triangle tree nodes, with T and R only
 GEQRT_MS = {True: {1: 18.4, 2: 21.5, 4: 27.1, 8: 36.4, 16: 60.0, 32: 105.0}, False: {1: 16.5, 2: 19.5, 4: 24.0, 8: 31.0, 16: 47.2, 32: 77.8}}
@@ -57,7 +62,7 @@ def batched_ms(table, count):
     return total
 
 
-def simulate_cholesky(world, nb, link_gbs, kernel_ms, host_us):
+def simulate_cholesky(world, nb, link_gbs, kernel_ms, host_us, host_own_us=HOST_US_PER_OWN_TASK):
     from numpywren_amd import alg_wrappers
     from numpywren_amd.dist import process_grid
     from numpywren_amd.matrix import BigMatrix
@@ -94,8 +99,14 @@ def simulate_cholesky(world, nb, link_gbs, kernel_ms, host_us):
                 heapq.heappush(ready, (-prio[c.key], c.index))
     assert len(seq) == len(tasks)
     pos = {t.index: n for n, t in enumerate(seq)}
-    host_ms = host_us * 1e-3 if world > 1 else 0.1      # one GPU: job_runner's own ~0.1 ms per task, no plan walk
     rank_of = {t.index: owner(*t.writes[0]) for t in tasks}
+    # when rank r's walk has passed position p: bookkeeping for every position, the enqueue work for its own tasks
+    reach = [[0.0] * len(seq) for _ in range(world)]
+    for r in range(world):
+        clock = 0.0
+        for n_, t in enumerate(seq):
+            clock += host_us * 1e-3 + (host_own_us * 1e-3 if rank_of[t.index] == r else 0.0)
+            reach[r][n_] = clock
     xfer_ms = TILE_BYTES / (link_gbs * 1e9) * 1e3
     finish = {}                       # task index -> finish time
     arrive = {}                       # (tile, rank) -> arrival time
@@ -112,7 +123,7 @@ def simulate_cholesky(world, nb, link_gbs, kernel_ms, host_us):
         for r in range(world):
             best = None
             for t in pending[r][:64]:      # (a GPU runs ahead of the common sequence by a bounded window)
-                ok, when = True, (pos[t.index] + 1) * host_ms     # the host's walk has to have reached the task
+                ok, when = True, reach[r][pos[t.index]]           # the host's walk has to have reached the task
                 for rd in t.reads:
                     w = compiled.writer_of(*rd)
                     if w is None:
@@ -149,7 +160,7 @@ def simulate_cholesky(world, nb, link_gbs, kernel_ms, host_us):
     n = nb * 4096
     busy = sum(cost(t) for t in tasks)
     return {"gpus": world, "grid": f"{pr}x{pc}", "ms": round(total, 1), "tflops": round(n ** 3 / 3 / (total * 1e-3) / 1e12, 1),
-            "host_walk_ms": round(len(seq) * host_ms, 1), "sum_of_kernel_ms": round(busy, 1),
+            "host_walk_ms": round(max(reach[r][-1] for r in range(world)), 1), "sum_of_kernel_ms": round(busy, 1),
             "efficiency_vs_sum": round(busy / world / total, 3), "GB_moved": round(sent_bytes / 1e9, 1)}
 
 
@@ -201,15 +212,19 @@ def predict_gemm(world, nb, link_gbs):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--link-gbs", type=float, default=64.0)
-    ap.add_argument("--host-us", type=float, default=HOST_US_PER_POSITION)
+    ap.add_argument("--host-us", type=float, default=HOST_US_PER_POSITION, help="host bookkeeping per position of the common sequence, every rank")
+    ap.add_argument("--host-own-us", type=float, default=HOST_US_PER_OWN_TASK, help="host work per task a rank runs itself")
     ap.add_argument("--tiles", type=int, default=16)
     ap.add_argument("--write", action="store_true", help="write profiles/predicted_scaling.json")
     a = ap.parse_args()
     out = {"note": "PREDICTED from measured single-GPU kernel times by tools/predict_scaling.py; never measured on more than one GPU",
-           "link_GBps_per_direction": a.link_gbs, "host_us_per_position": a.host_us, "workloads": {}}
+           "link_GBps_per_direction": a.link_gbs, "host_us_per_position": a.host_us, "host_us_per_own_task": a.host_own_us,
+           "host_model_source": "tools/dist_host_split.py on one MI355X, real backend (profiles/r05_dist_host_split.md): world of one "
+                                "61 ms measured / 61.2 modelled, rank 0 of 8 24 - 29 ms measured / 21.8 + 3 (prologue) modelled",
+           "workloads": {}}
     rows = []
     for w in (1, 2, 4, 8):
-        rows.append(simulate_cholesky(w, a.tiles, a.link_gbs, KERNEL_MS_1GPU if w == 1 else KERNEL_MS_3STREAMS, a.host_us))
+        rows.append(simulate_cholesky(w, a.tiles, a.link_gbs, KERNEL_MS_1GPU if w == 1 else KERNEL_MS_3STREAMS, a.host_us, a.host_own_us))
         print("chol  ", rows[-1])
     out["workloads"]["chol"] = {"what": "65536^2 fp64 Cholesky, 4096^2 tiles (bench.py --gpus N)",
                                 "tflops_by_gpus": {str(r["gpus"]): r["tflops"] for r in rows}, "rows": rows,
