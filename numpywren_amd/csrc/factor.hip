@@ -1178,8 +1178,24 @@ inline int64_t split(int64_t n) {  // first-half size: multiple of NB, roughly n
 }
 
 inline size_t winv_group_elems(int64_t n) { return (size_t)ceil_div(n, LW) * LW * LW; }
+// Behind the groups and their scratch: M = the strictly lower LW-blocks of L, each block row g premultiplied with its group's
+// inverse, M[g, h] = inv(L_gg) L[g, h] (h < g), rows LW .. n, columns 0 .. n - LW, ld = n - LW -- what the fused solve
+// (trsm_fused) multiplies with instead of L.  Only for factors made of whole groups (n a multiple of LW, at least two).
+// OFF by default ($NPW_TRSM_FUSED=1 turns it on): measured in round 5 (profiles/r05_step_level_experiments.md), the one launch
+// takes 338 us against 4 x 93 for the four group products it replaces -- 1024 tiles of equal length classes finish, and write
+// their 128 KiB each, at the same moments -- and M costs 0.30 ms per factor, which the 3 + 2 + 1 solves per factor of the
+// 16384^2 problem never earn back (27.19 against 26.5 ms per step).
+inline bool trsm_fused_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("NPW_TRSM_FUSED");
+        return e != nullptr && atoi(e) != 0;
+    }();
+    return on;
+}
+inline bool winv_has_m(int64_t n) { return trsm_fused_enabled() && n % LW == 0 && n >= 2 * LW; }
+inline size_t winv_m_offset(int64_t n) { return winv_group_elems(n) + (size_t)ceil_div(n, LW) * (LW / 2) * (LW / 2); }
 inline size_t winv_bytes(int64_t n) {
-    return (winv_group_elems(n) + (size_t)ceil_div(n, LW) * (LW / 2) * (LW / 2)) * sizeof(double);
+    return (winv_m_offset(n) + (winv_has_m(n) ? (size_t)(n - LW) * (n - LW) : 0)) * sizeof(double);
 }
 
 // Fill the off-diagonal part of every LW x LW group of Winv by doubling steps (batched GEMMs):
@@ -1221,6 +1237,21 @@ int complete_groups(int64_t n, const double* L, int64_t ldl, double* Winv, hipSt
                           Winv + (int64_t)half * LW, LW, q, s);
         if (rc) return rc;
     }
+    if (winv_has_m(n)) {
+        // M[g, 0 : g LW] = inv(L_gg) L[g, 0 : g LW], block row by block row (inv(L_gg) is lower triangular: row tile m0 stops
+        // at k = m0 + BM).  6.4e9 flop for a 4096^2 factor, once per factor; every solve with it then runs its four group
+        // products as ONE balanced launch (trsm_fused).
+        // One launch: blockdiag(W_1 .. W_{G-1}) times the block lower triangle of L[LW :, 0 : n - LW] (a_blockdiag; three
+        // launches of 64 / 128 / 192 tiles, one per block row, each under-filled the chip: 0.28 ms instead of 0.1).
+        double* M = Winv + winv_m_offset(n);
+        const int64_t ldm = n - LW;
+        GemmOpts o;
+        o.a_blockdiag = LW;
+        o.force_big = true;
+        int rc = gemm<double>('N', 'N', n - LW, n - LW, n - LW, 1.0, Winv + (size_t)LW * LW, LW, L + LW * ldl, ldl, 0.0, nullptr, 0, M,
+                              ldm, o, s);
+        if (rc) return rc;
+    }
     return NPW_OK;
 }
 
@@ -1243,6 +1274,8 @@ struct TrsmCtx {
     int64_t c0;  // absolute column offset of X's / B's / T's column 0 inside L (potrf panels)
     hipStream_t s;
     bool groups_ready = false;  // Winv's full LW groups are complete inverses (complete_groups ran)
+    const double* M = nullptr;  // ... and behind them the premultiplied strictly lower blocks of L (winv_has_m), ld = ldm
+    int64_t ldm = 0;
     // several right-hand sides that share L (the trsm tasks of one block column of the Cholesky DAG) as ONE solve: every
     // GEMM of the recursion runs as a batch with blockIdx.z = right-hand side; B, X, T above are those of problem 0 and
     // problem z's are dB[z], dX[z], dT[z] elements further (separate allocations: no constant stride)
@@ -1313,6 +1346,40 @@ int trsm_rec(const TrsmCtx& c, int64_t coff, int64_t n, bool touched) {
                       trsm_batch(c, c.dX, touched ? c.dT : c.dB, c.dT), c.s);
     if (rc) return rc;
     return trsm_rec(c, coff + n1, n2, true);
+}
+
+// The solve with a factor made of whole groups (n = G LW, G >= 2), out of place:  X = B inv(L)^T  as
+//     X   = B blockdiag(W_0 .. W_{G-1})^T                       W_g = inv(L_gg): ONE launch over all groups
+//     X_g -= sum_{h < g} X_h M[g, h]^T  (recursively, in place)   M[g, h] = W_g L[g, h], kept with the factor
+// instead of  X_g = (B_g - sum_h X_h L[g, h]^T) W_g^T  group after group.  The same flops and the same updates (with M in the
+// place of L), but the G triangular products no longer depend on one another: they were G launches of 4.6e9 flop each on
+// 64 x 64 tiles whose k ranges run from 64 to 1024 -- 42 - 45 TFLOP/s, a third of a 4096-wide solve's time for a quarter of
+// its flops -- and are one launch of 1024 full 128 x 128 tiles handed out longest first on the pinned
+// k loop.  4096-wide: 7 launches -> 4.
+int trsm_fused_updates(const TrsmCtx& c, int64_t coff, int64_t n) {
+    if (n <= LW) return NPW_OK;
+    const int64_t n1 = ((n / LW) / 2) * LW, n2 = n - n1;   // whole groups on both sides
+    int rc = trsm_fused_updates(c, coff, n1);
+    if (rc) return rc;
+    const double* M21 = c.M + (coff + n1 - LW) * c.ldm + coff;
+    double* X2 = c.X + coff + n1;
+    rc = gemm<double>('N', 'T', c.m, n2, n1, -1.0, c.X + coff, c.ldx, M21, c.ldm, 1.0, X2, c.ldx, X2, c.ldx,
+                      trsm_batch(c, c.dX, c.dX, c.dX), c.s);
+    if (rc) return rc;
+    return trsm_fused_updates(c, coff + n1, n2);
+}
+
+inline bool trsm_can_fuse(const TrsmCtx& c, int64_t n) {
+    return trsm_fused_enabled() && c.groups_ready && c.M != nullptr && c.c0 == 0 && winv_has_m(n) && c.m % 128 == 0 && (const void*)c.B != (const void*)c.X;
+}
+
+int trsm_fused(const TrsmCtx& c, int64_t n) {
+    GemmOpts g = trsm_batch(c, c.dB, nullptr, c.dX);
+    g.b_blockdiag = LW;
+    g.force_big = true;
+    int rc = gemm<double>('N', 'T', c.m, n, n, 1.0, c.B, c.ldb, c.Winv, LW, 0.0, nullptr, 0, c.X, c.ldx, g, c.s);
+    if (rc) return rc;
+    return trsm_fused_updates(c, 0, n);
 }
 
 // Compute units a launch on `s` can be resident on: the device's, or fewer for a stream created with a CU mask
@@ -1477,6 +1544,11 @@ int npw_dtrsm_rltn_inv(int64_t m, int64_t n, const double* L, int64_t ldl, const
     TrsmCtx c{m, L, ldl, B, ldb, X, ldx, static_cast<double*>(workspace), n, Winv, 0, as_stream(stream)};
     c.groups_ready = true;  // Winv comes from npw_dtrtri_diag or npw_dpotrf_lower, which both complete the groups
     c.skip = skip_y;
+    if (winv_has_m(n)) {
+        c.M = Winv + winv_m_offset(n);
+        c.ldm = n - LW;
+    }
+    if (trsm_can_fuse(c, n)) return trsm_fused(c, n);
     return trsm_rec(c, 0, n, false);
 }
 
@@ -1513,6 +1585,11 @@ int npw_dtrsm_rltn_inv_batched(int count, int64_t m, int64_t n, const double* L,
         c.skip = skip_y[0];
         c.dskip = dS;
     }
+    if (winv_has_m(n)) {
+        c.M = Winv + winv_m_offset(n);
+        c.ldm = n - LW;
+    }
+    if (trsm_can_fuse(c, n)) return trsm_fused(c, n);
     return trsm_rec(c, 0, n, false);
 }
 

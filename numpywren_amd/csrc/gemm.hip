@@ -111,11 +111,16 @@ struct GemmParams {
     int batch_inner;                                  // two-level batch: z -> (z / inner, z % inner)
     int64_t batch2_a, batch2_b, batch2_c, batch2_d;
     int b_lower_tri;                                  // k range of column tile n0 ends at n0 + BN
-    int pad_layout_;                                  // unused; without it the arrays below start 8 bytes earlier and the
-                                                      // 128 x 128 trailing update measures 0.3 % slower (1.9233 vs 1.9176 ms)
+    int b_blockdiag;                                  // > 0: op(B) = W^T, W block diagonal with lower triangular blocks of this width;
+                                                      // < 0: op(A) = W instead (width = -b_blockdiag)
+                                                      // (in the slot of a former pad word: without a word here the arrays below
+                                                      // start 8 bytes earlier and the 128 x 128 trailing update measured 0.3 %
+                                                      // slower, 1.9233 vs 1.9176 ms)
     int k_from_diag;                                  // k range of tile (m0, n0) starts at max(m0, n0) (trapezoidal operands)
     int a_upper_tri;                                  // k range of row tile m0 starts at m0 (op(A) upper triangular)
     int use_delta;                                    // irregular batch: element offsets per problem instead of strides
+    int a_lower_tri;                                  // k range of row tile m0 ends at m0 + BM (op(A) lower triangular)
+                                                      // (sixth int of the group: fills the padding before the int64 arrays)
     int64_t da[16], db[16], dc[16], dd[16];
     int64_t ds0[16], ds1[16];                         // ... and of the skip flags (int32 units)
 };
@@ -232,6 +237,17 @@ __global__ __launch_bounds__(128 * NW, 2) void gemm_kernel(const GemmParams<T> p
     } else if (p.lower_only == 3) {  // strictly lower tiles: the triangle of order tiles - 1, one row down
         block_to_tile_tri(p.tiles_m - 1, spread, tile_m, tile_n);
         tile_m += 1;
+    } else if (p.b_blockdiag > 0) {
+        // block-diagonal triangular B: the tiles' k ranges are BN, 2 BN, ... b_blockdiag in every diagonal block.  Block
+        // ids in order of falling length -- class 0 = the last column tile of every block, all tile rows, then class 1 ...
+        // -- so the dispatcher, which starts workgroups in id order as slots free up, does longest-first list scheduling:
+        // a slot that ran a long tile picks up a short one (1024 tiles on 512 slots: 1024 + 128 = 896 + 256 = ...)
+        const int tpg = p.b_blockdiag / BN;
+        const int per_class = p.tiles_m * (p.tiles_n / tpg);
+        const int b = (int)blockIdx.x;
+        const int cls = b / per_class, rem = b - cls * per_class;
+        tile_m = rem % p.tiles_m;
+        tile_n = (rem / p.tiles_m) * tpg + (tpg - 1 - cls);
     } else {
         block_to_tile(p.tiles_m, p.tiles_n, spread, tile_m, tile_n);
         // triangular B: the k range grows with the tile column -- longest tiles first, the short ones fill the tail
@@ -252,6 +268,24 @@ __global__ __launch_bounds__(128 * NW, 2) void gemm_kernel(const GemmParams<T> p
     if (p.a_upper_tri) kb = max(kb, (m0 / BK) * BK);           // T1 * X with T1 upper triangular: columns left of the diagonal are zero
     int kend = p.k_chunk > 0 ? min(p.K, kb + p.k_chunk) : p.K;
     if (p.b_lower_tri) kend = min(kend, n0 + BN);  // rows of W^T below the diagonal block are zero
+    if (p.a_lower_tri) kend = min(kend, m0 + BM);  // columns of op(A) right of the diagonal block are zero
+    if (p.b_blockdiag > 0) {
+        // W's block g = n0 / width sits at B + g width^2 with ld = width: element (n, k) of the virtual n x n matrix is at
+        // B + n ld + (k - g width), and the block only has k in [g width, n0 + BN)
+        const int g0 = (n0 / p.b_blockdiag) * p.b_blockdiag;
+        kb = max(kb, g0);
+        kend = min(kend, n0 + BN);
+        p.B -= g0;
+    } else if (p.b_blockdiag < 0) {
+        // the same W on the left: element (r, k) at A + r ld + (k - g width), k in [g width, m0 + BM); tiles right of the
+        // block's own column are nobody's business
+        const int w = -p.b_blockdiag;
+        const int g0 = (m0 / w) * w;
+        if (n0 >= g0 + w) return;
+        kb = max(kb, g0);
+        kend = min(kend, m0 + BM);
+        p.A -= g0;
+    }
     int nk = (kend - kb + BK - 1) / BK;
     if ((p.skip0 && *p.skip0) || (p.skip1 && *p.skip1)) nk = 0;
 
@@ -638,7 +672,8 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
     NPW_REQUIRE(D != nullptr, "gemm: D is NULL");
     NPW_REQUIRE(beta == T(0) || C != nullptr, "gemm: C is NULL with beta != 0");
     NPW_REQUIRE(k == 0 || (A != nullptr && B != nullptr), "gemm: A/B NULL");
-    NPW_REQUIRE(lda >= (ta ? m : k) && ldb >= (tb ? k : n) && ldd >= n && (beta == T(0) || ldc >= n),
+    // (a block diagonal operand -- b_blockdiag / a_blockdiag -- is stored as its diagonal blocks back to back: ld = block width)
+    NPW_REQUIRE((lda >= (ta ? m : k) || opts.a_blockdiag > 0) && (ldb >= (tb ? k : n) || opts.b_blockdiag > 0) && ldd >= n && (beta == T(0) || ldc >= n),
                 "gemm: leading dimension too small (m=%lld n=%lld k=%lld lda=%lld ldb=%lld ldc=%lld "
                 "ldd=%lld)",
                 (long long)m, (long long)n, (long long)k, (long long)lda, (long long)ldb,
@@ -720,7 +755,14 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
     p.batch2_c = opts.batch2_c;
     p.batch2_d = opts.batch2_d;
     p.b_lower_tri = opts.b_lower_tri ? 1 : 0;
-    p.pad_layout_ = 0;
+    p.b_blockdiag = opts.b_blockdiag > 0 ? opts.b_blockdiag : -opts.a_blockdiag;
+    NPW_REQUIRE(opts.a_blockdiag == 0 || (opts.b_blockdiag == 0 && !ta && opts.a_blockdiag % 128 == 0 && m % opts.a_blockdiag == 0 && k == m &&
+                                          lda == opts.a_blockdiag && opts.force_big && !opts.lower_only && opts.k_chunk_ == 0 && n % 128 == 0),
+                "gemm: a_blockdiag needs op(A) = N, whole 128-column tiles, m == k a multiple of the block width, lda == width and force_big");
+    p.a_lower_tri = opts.a_lower_tri ? 1 : 0;
+    NPW_REQUIRE(opts.b_blockdiag == 0 || (tb && !ta && opts.b_blockdiag % 128 == 0 && n % opts.b_blockdiag == 0 && k == n &&
+                                          ldb == opts.b_blockdiag && opts.force_big && !opts.lower_only && opts.k_chunk_ == 0 && m % 128 == 0),
+                "gemm: b_blockdiag needs op(A) = N, op(B) = T, whole 128-row tiles, n == k a multiple of the block width, ldb == width and force_big");
     p.k_from_diag = opts.k_from_diag ? 1 : 0;
     p.a_upper_tri = opts.a_upper_tri ? 1 : 0;
     p.use_delta = 0;

@@ -68,6 +68,15 @@ struct GemmOpts {
     bool b_lower_tri = false;  // op(B) = W^T with W (n x k) lower triangular: column tile n0 only needs k < n0 + BN
     bool k_from_diag = false;  // op(A)^T, op(B) (k x m, k x n) lower trapezoidal: tile (m0, n0) only needs k >= max(m0, n0)
     bool a_upper_tri = false;  // op(A) (m x k) upper triangular: row tile m0 only needs k >= m0
+    bool a_lower_tri = false;  // op(A) (m x k) lower triangular: row tile m0 only needs k < m0 + BM
+    // op(B) = W^T with W block diagonal: `b_blockdiag`-wide lower triangular diagonal blocks stored back to back (block g at
+    // B + g * b_blockdiag^2, ldb = b_blockdiag).  Column tile n0 of block g sums over k in [g * b_blockdiag, n0 + BN).  One launch
+    // over all blocks, 128 x 128 tiles handed out longest first (trsm's group products: factor.hip trsm_fused).
+    int b_blockdiag = 0;
+    // op(A) = W, the same block diagonal matrix on the left (op(A) = N, lda = a_blockdiag): row tile m0 of block g sums over k in
+    // [g * a_blockdiag, m0 + BM), and output tiles right of block column g (n0 >= (g + 1) * a_blockdiag) are not computed at all
+    // -- W times the block lower triangle of op(B), one launch (the factor's premultiplied blocks: factor.hip complete_groups).
+    int a_blockdiag = 0;
     // Irregular batch: problem z's operand is (pointer of problem 0) + delta_x[z] ELEMENTS instead of z * batch_x
     // (tiles of one batch live in separate allocations).  Arrays of `batch` entries (<= 16) or NULL.
     const int64_t* delta_a = nullptr;

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import npw_oracle as oracle
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 from numpywren_amd import kernels
 
 pytestmark = pytest.mark.gpu
@@ -516,6 +516,39 @@ def test_trsm_batched_equals_one_by_one(n, m, count):
         np.testing.assert_allclose(xb, ref, rtol=1e-9, atol=1e-10)
     assert not be.to_host(got[-1]).any()
     del junk
+
+
+def test_trsm_fused_form_matches_the_recursive_one():
+    """$NPW_TRSM_FUSED=1 (off by default: profiles/r05_step_level_experiments.md): the solve with a factor made of whole
+    1024-wide groups as ONE block-diagonal triangular product (gemm's b_blockdiag, 128 x 128 tiles handed out longest first)
+    followed by in-place updates with the premultiplied blocks inv(L_gg) L[g, h] (a_blockdiag) -- the GEMM options and the
+    factor's extra blocks stay tested although no default path takes them.  In a subprocess: the switch is read once."""
+    import subprocess
+    import sys
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import npw_oracle as oracle
+from numpywren_amd import kernels
+be = kernels.get_backend()
+for n, m, count in ((2048, 1024, 1), (4096, 512, 3), (3072, 256, 2)):
+    rng = np.random.default_rng(n + m)
+    G = rng.standard_normal((n, 256))
+    Lh = np.linalg.cholesky(G @ G.T + n * np.eye(n))
+    L, _ = be.chol(be.to_device(Lh @ Lh.T))
+    Ys = [rng.standard_normal((m, n)) for _ in range(count)]
+    tiles = [be.to_device(y) for y in Ys]
+    got = be.trsm_batched(L, tiles) if count > 1 else [be.trsm(L, tiles[0])]
+    Ld = np.tril(be.to_host(L))
+    for y, x in zip(Ys, got):
+        xh = be.to_host(x)
+        assert np.abs(xh @ Ld.T - y).max() <= 1e-11 * np.abs(y).max() * n ** 0.5, (n, np.abs(xh @ Ld.T - y).max())
+        np.testing.assert_allclose(xh, oracle.trsm(Ld, y), rtol=1e-8, atol=1e-9)
+print("fused ok")
+""" % (ROOT, os.path.join(ROOT, "oracle"))
+    env = dict(os.environ, NPW_TRSM_FUSED="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "fused ok" in out.stdout, (out.stdout + out.stderr)[-3000:]
 
 
 def test_trsm_tasks_of_a_block_column_run_as_one_batch(hbm_store, monkeypatch):
