@@ -86,9 +86,10 @@ int npw_stream_create(npw_stream_t* stream, int high_priority);
  * the latency-bound panel kernels of the critical path always find a slot.               */
 int npw_stream_create_masked(npw_stream_t* stream, const uint32_t* cu_mask, int words);
 /* Also retires what the library keeps per stream (the helper streams of the factorisations, the cached CU count): a later
- * stream that is handed the same handle starts clean.  The stream must be idle.  Create CU-masked streams once and keep
- * them: create / destroy cycles of masked streams hang inside the HIP runtime of ROCm 7.2 now and then (observed about
- * every tenth cycle, with nothing but one GEMM on the stream in between). */
+ * stream that is handed the same handle starts clean.  The stream must be idle.  A CU-MASKED stream is not handed back to the
+ * HIP runtime but parked (synchronised, with its helpers) and given out again by the next npw_stream_create_masked with the
+ * same mask: create / destroy cycles of masked streams hang inside the HIP runtime of ROCm 7.2 now and then (observed about
+ * every tenth cycle, with nothing but one GEMM on the stream in between), so the library never runs one. */
 int npw_stream_destroy(npw_stream_t stream);
 /* compute_units: the compute units `stream` may run on (its CU mask; the whole device for a plain stream).
  * resident_units: what the resident-grid kernels (npw_dgeqrt_batched, npw_dtpqrt_batched, npw_dpotrf_lower: every workgroup
