@@ -376,7 +376,9 @@ def step_stats(step_ms, mean_ms, what="ms_per_step"):
 
 
 def cholesky_residual(be, X, O, nb, full=False):
-    """|| A - L L^T ||_F / || A ||_F on the device: all tiles (full=True) or the tile (1, 1)."""
+    """|| A - L L^T ||_F / || A ||_F on the device: all tiles (full=True) or the tile (1, 1).  A PROPERTY check computed with
+    this build's own GEMM (be.gemm) -- not an independent product: that GEMM is checked against the oracle at 4096^2 in
+    tests/test_tile4096_gpu.py, and the factor itself against np.linalg.cholesky / the oracle at the sizes those finish."""
     num = den = 0.0
     todo = [(i, j) for i in range(nb) for j in range(i + 1)] if full else [(1, 1) if nb > 1 else (0, 0)]
     for i, j in todo:

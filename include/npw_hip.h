@@ -136,7 +136,9 @@ int npw_sgemm(char transA, char transB, int64_t m, int64_t n, int64_t k, float a
  * and each of them also writes its mirror tile (S is read at both positions: the result is the full
  * S - X X^T for any S, symmetric or not).
  * workspace: npw_dgemm_nt_sub_workspace_bytes(m, n, k) bytes (0 unless the symmetric path applies), may
- * be NULL: it lets the diagonal blocks of the symmetric path run k-split over the whole chip.
+ * be NULL: with it the diagonal blocks of the symmetric path ride in the pair launch as short k chunks (the slots the
+ * pairs leave free work through them, the rest fills the launch's tail) and are summed in a fixed order by one small
+ * launch; without it they are a second, k-split launch of their own.
  * Replaces kernels.syrk (reference numpywren/kernels.py:212-215) -- the Cholesky
  * trailing update, the north-star kernel.                                      */
 size_t npw_dgemm_nt_sub_workspace_bytes(int64_t m, int64_t n, int64_t k);
@@ -149,7 +151,8 @@ int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t l
  * handed over together by the executor.  Arrays of `count` device pointers (16-byte aligned tiles; D[z] may alias
  * S[z]); skip_x / skip_y: arrays of per-problem flags or both NULL.  Every problem is computed exactly as
  * npw_dgemm_nt_sub computes it; the symmetric route (X[z] == Y[z]) is taken when ALL problems qualify -- callers batch
- * diagonal and off-diagonal tiles separately.  workspace: npw_dgemm_nt_sub_workspace_bytes(m, n, k) bytes or NULL. */
+ * diagonal and off-diagonal tiles separately.  workspace: `count` x npw_dgemm_nt_sub_workspace_bytes(m, n, k) bytes (every
+ * problem's diagonal blocks are in flight in the one launch) or NULL. */
 int npw_dgemm_nt_sub_batched(int count, int64_t m, int64_t n, int64_t k, const double* const* S, int64_t lds,
                              const double* const* X, int64_t ldx, const double* const* Y, int64_t ldy,
                              double* const* D, int64_t ldd, const int32_t* const* skip_x,

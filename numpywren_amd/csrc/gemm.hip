@@ -123,6 +123,9 @@ struct GemmParams {
                                                       // (sixth int of the group: fills the padding before the int64 arrays)
     int64_t da[16], db[16], dc[16], dd[16];
     int64_t ds0[16], ds1[16];                         // ... and of the skip flags (int32 units)
+    // (at the END: nothing above moves)  tag 2: diagonal blocks in the same launch -- see GemmOpts::diag_ws
+    T* diag_ws;
+    int diag_split, diag_chunk;
 };
 
 // XCD-aware + grouped mapping of the linear block id to an output tile.
@@ -228,11 +231,21 @@ __global__ __launch_bounds__(128 * NW, 2) void gemm_kernel(const GemmParams<T> p
     // LDS address space and emit flat_load / flat_store (+ 64-bit address arithmetic) for every fragment.
     constexpr int STAGE = A_ELEMS + B_ELEMS;
 
-    int tile_m, tile_n;
+    int tile_m = 0, tile_n = 0;
     // (only when the launch takes several rounds of workgroups: within one round everybody is resident anyway and the
     //  contiguous map's L2 locality is worth more)
     const bool spread = (p.b_lower_tri || p.k_from_diag || p.a_upper_tri) && (gridDim.x * gridDim.y * gridDim.z > 1024u);
-    if (p.lower_only == 2) {
+    int diag_part = -1;   // >= 0: this workgroup is a k chunk of a diagonal block (tag 2 with diag_ws), not a tile pair
+    if constexpr (TAG == 2) {
+        const int ntri = p.tiles_m * (p.tiles_m - 1) / 2;
+        if ((int)blockIdx.x >= ntri) {
+            const int e = (int)blockIdx.x - ntri;
+            tile_m = tile_n = e / p.diag_split;
+            diag_part = e - tile_m * p.diag_split;
+        }
+    }
+    if (diag_part >= 0) {
+    } else if (p.lower_only == 2) {
         block_to_tile_tri(p.tiles_m, spread, tile_m, tile_n);
     } else if (p.lower_only == 3) {  // strictly lower tiles: the triangle of order tiles - 1, one row down
         block_to_tile_tri(p.tiles_m - 1, spread, tile_m, tile_n);
@@ -285,6 +298,18 @@ __global__ __launch_bounds__(128 * NW, 2) void gemm_kernel(const GemmParams<T> p
         kb = max(kb, g0);
         kend = min(kend, m0 + BM);
         p.A -= g0;
+    }
+    if constexpr (TAG == 2) {
+        if (diag_part >= 0) {
+            // raw partial product of the block's k chunk into the scratch: no alpha, no C, 128 x 128 with ld = BN
+            kb = diag_part * p.diag_chunk;
+            kend = min(p.K, kb + p.diag_chunk);
+            p.alpha = T(1);
+            p.beta = T(0);
+            p.ldd = BN;
+            p.D = p.diag_ws + (((int64_t)blockIdx.z * p.tiles_m + tile_m) * p.diag_split + diag_part) * (int64_t)(BM * BN) -
+                  ((int64_t)m0 * BN + n0);
+        }
     }
     int nk = (kend - kb + BK - 1) / BK;
     if ((p.skip0 && *p.skip0) || (p.skip1 && *p.skip1)) nk = 0;
@@ -613,7 +638,9 @@ int launch(const GemmParams<T>& p, hipStream_t stream) {
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
                 tagged_attr[p.tag] = true;
             }
-            hipLaunchKernelGGL(tagged, dim3(nwg, nsplit, nbatch), dim3(256), smem, stream, p);
+            // (tag 2 with diag_ws: the diagonal blocks' k chunks ride behind the tile pairs)
+            const int extra = (p.tag == 2 && p.diag_ws != nullptr) ? p.tiles_m * p.diag_split : 0;
+            hipLaunchKernelGGL(tagged, dim3(nwg + extra, nsplit, nbatch), dim3(256), smem, stream, p);
             NPW_LAUNCH_CHECK();
             return NPW_OK;
         }
@@ -784,6 +811,15 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
         }
     }
     p.tag = opts.tag;
+    p.diag_ws = nullptr;
+    p.diag_split = p.diag_chunk = 0;
+    if (opts.diag_ws != nullptr && opts.diag_split > 1) {
+        NPW_REQUIRE(opts.tag == 2 && opts.strict_lower && opts.k_chunk_ == 0 && k % (16 * opts.diag_split) == 0,
+                    "gemm: diag_ws goes with the symmetric (tag 2) product and k a multiple of 16 * diag_split");
+        p.diag_ws = static_cast<T*>(opts.diag_ws);
+        p.diag_split = opts.diag_split;
+        p.diag_chunk = (int)(k / opts.diag_split);
+    }
     p.k_chunk = opts.k_chunk_;
     p.split_stride = opts.k_chunk_ > 0 ? m * n : 0;
 
@@ -886,7 +922,21 @@ int npw_sgemm(char transA, char transB, int64_t m, int64_t n, int64_t k, float a
 }
 
 namespace {
-constexpr int kDiagSplit = 8;  // k chunks of the diagonal-block launch of the symmetric trailing update
+constexpr int kDiagSplit = 8;  // k chunks of the diagonal-block launch of the symmetric trailing update (the separate-launch form)
+// ... and of the form that rides in the pair launch (GemmOpts::diag_ws): 16 chunks of k / 16 -- 60 us each for k = 4096, short
+// enough that what the free slots have not worked off when the pairs finish is one more short round on the whole chip
+constexpr int kDiagSplitFused = 16;
+bool diag_fused_on() {
+    static const bool on = [] {
+        const char* e = getenv("NPW_SYRK_DIAG_FUSED");
+        return e == nullptr || atoi(e) != 0;
+    }();
+    return on;
+}
+bool diag_fused_ok(int64_t m, int64_t k, const void* workspace) {
+    return diag_fused_on() && workspace != nullptr && m >= 1024 && k >= 1024 && k % (16 * kDiagSplitFused) == 0 &&
+           (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
+}
 // X == Y takes the symmetric route when the tagged full-tile kernel applies: square, whole 128 x 128 tiles, k a multiple
 // of the k-tile, 16-byte aligned rows; big enough that halving the tile count matters.
 bool nt_sub_symmetric(int64_t m, int64_t n, int64_t k, const double* X, int64_t ldx, const double* Y, int64_t ldy) {
@@ -898,6 +948,16 @@ bool nt_sub_symmetric(int64_t m, int64_t n, int64_t k, const double* X, int64_t 
 size_t npw_dgemm_nt_sub_workspace_bytes(int64_t m, int64_t n, int64_t k);
 
 namespace {
+// the diagonal blocks' partial products left in `partials` by the pair launch (GemmOpts::diag_ws), summed in a fixed order:
+// D_block = S_block - sum of the chunks
+int nt_sub_diag_reduce(int64_t m, const double* S, int64_t lds, double* D, int64_t ldd, const double* partials, hipStream_t stream) {
+    hipLaunchKernelGGL(npw::splitk_reduce_kernel<double>, dim3(1, 128, (unsigned)(m / 128)), dim3(128), 0, stream, kDiagSplitFused, partials,
+                       (int64_t)128 * 128, (int64_t)128, (int64_t)128, -1.0, 1.0, S, lds, D, ldd, (int64_t)128 * (lds + 1),
+                       (int64_t)128 * (ldd + 1));
+    NPW_LAUNCH_CHECK();
+    return NPW_OK;
+}
+
 // the m / 128 diagonal 128 x 128 blocks of  D = S - X X^T  (the symmetric route's second launch)
 int nt_sub_diag_blocks(int64_t m, int64_t k, const double* S, int64_t lds, const double* X, int64_t ldx, double* D, int64_t ldd,
                        const int32_t* skip_x, const int32_t* skip_y, void* workspace, hipStream_t stream) {
@@ -921,7 +981,7 @@ int nt_sub_diag_blocks(int64_t m, int64_t k, const double* S, int64_t lds, const
 
 size_t npw_dgemm_nt_sub_workspace_bytes(int64_t m, int64_t n, int64_t k) {
     if (m != n || m % 128 != 0 || m < 1024 || k < 1024) return 0;
-    return (size_t)(m / 128) * kDiagSplit * 128 * 128 * sizeof(double);
+    return (size_t)(m / 128) * (kDiagSplit > kDiagSplitFused ? kDiagSplit : kDiagSplitFused) * 128 * 128 * sizeof(double);
 }
 
 int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t lds,
@@ -946,8 +1006,16 @@ int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t l
     // 2 workgroups share a CU, so the chip holds 512 tiles at a time: the 496 strictly-lower tiles of a 4096^2
     // output are one full wave of work, the 32 diagonal tiles would be a second, nearly empty one.  They go into
     // their own small batched launch instead (full 128 x 128 blocks).
+    // ... or, with a workspace, ride in the pair launch as short k chunks behind the pairs (GemmOpts::diag_ws): the 16 slots
+    // the pairs leave free work through them meanwhile, the rest fills the tail; then one small reduction launch.
+    const bool fused = diag_fused_ok(m, k, workspace);
+    if (fused) {
+        o.diag_ws = workspace;
+        o.diag_split = kDiagSplitFused;
+    }
     int rc = npw::gemm<double>('N', 'T', m, n, k, -1.0, X, ldx, Y, ldy, 1.0, S, lds, D, ldd, o, npw::as_stream(stream));
     if (rc) return rc;
+    if (fused) return nt_sub_diag_reduce(m, S, lds, D, ldd, static_cast<const double*>(workspace), npw::as_stream(stream));
     return nt_sub_diag_blocks(m, k, S, lds, X, ldx, D, ldd, skip_x, skip_y, workspace, npw::as_stream(stream));
 }
 
@@ -1000,8 +1068,23 @@ int npw_dgemm_nt_sub_batched(int count, int64_t m, int64_t n, int64_t k, const d
         o.delta_skip0 = ds0;
         o.delta_skip1 = ds1;
     }
+    // (symmetric, with a workspace of `count` x npw_dgemm_nt_sub_workspace_bytes: every problem's diagonal blocks ride in the
+    //  one launch, as in npw_dgemm_nt_sub; then a reduction launch per problem)
+    const bool fused = symmetric && diag_fused_ok(m, k, workspace);
+    if (fused) {
+        o.diag_ws = workspace;
+        o.diag_split = kDiagSplitFused;
+    }
     int rc = npw::gemm<double>('N', 'T', m, n, k, -1.0, X[0], ldx, Y[0], ldy, 1.0, S[0], lds, D[0], ldd, o, npw::as_stream(stream));
     if (rc || !symmetric) return rc;
+    if (fused) {
+        const size_t per_problem = (size_t)(m / 128) * kDiagSplitFused * 128 * 128;
+        for (int z = 0; z < count; ++z) {
+            rc = nt_sub_diag_reduce(m, S[z], lds, D[z], ldd, static_cast<const double*>(workspace) + z * per_problem, npw::as_stream(stream));
+            if (rc) return rc;
+        }
+        return NPW_OK;
+    }
     for (int z = 0; z < count; ++z) {   // (one workspace: the launches of one stream run one after the other)
         rc = nt_sub_diag_blocks(m, k, S[z], lds, X[z], ldx, D[z], ldd, skip_x ? skip_x[z] : nullptr, skip_y ? skip_y[z] : nullptr,
                                 workspace, npw::as_stream(stream));

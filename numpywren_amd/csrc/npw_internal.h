@@ -77,6 +77,12 @@ struct GemmOpts {
     // [g * a_blockdiag, m0 + BM), and output tiles right of block column g (n0 >= (g + 1) * a_blockdiag) are not computed at all
     // -- W times the block lower triangle of op(B), one launch (the factor's premultiplied blocks: factor.hip complete_groups).
     int a_blockdiag = 0;
+    // tag 2 (the symmetric trailing update) only: the diagonal 128 x 128 blocks ride in the same launch, cut into `diag_split`
+    // k chunks whose raw partial products go to diag_ws ([problem][block][chunk][128 x 128]); appended AFTER the tile pairs in
+    // block-id order, so that the slots the pairs leave free -- 16 of 512 for a 4096^2 tile -- work through them while the
+    // pairs run and the rest fills the launch's tail.  The caller sums the chunks in a fixed order (splitk_reduce).
+    void* diag_ws = nullptr;
+    int diag_split = 0;
     // Irregular batch: problem z's operand is (pointer of problem 0) + delta_x[z] ELEMENTS instead of z * batch_x
     // (tiles of one batch live in separate allocations).  Arrays of `batch` entries (<= 16) or NULL.
     const int64_t* delta_a = nullptr;

@@ -1072,7 +1072,7 @@ class HipBackend(object):
                     self._use(sh, problems[i][0], problems[i][1], problems[i][2], out)
                 ws = None
                 if sym:
-                    nbytes = self.lib.npw_dgemm_nt_sub_workspace_bytes(m, n, k)
+                    nbytes = self.lib.npw_dgemm_nt_sub_workspace_bytes(m, n, k) * count   # (per problem: npw_hip.h)
                     if nbytes:
                         ws = self.alloc(nbytes)
                         ws.streams.add(sh)
@@ -1328,6 +1328,8 @@ class HipBackend(object):
         # workgroup: 32 tiles of 4096 rows on the whole chip, the size every measurement of the batched form was made at)
         cus, resident = self.stream_cus(sh)
         cap = max(1, min((2 * cus) // ((m + 255) // 256), (2 * resident) // ((m + 511) // 512)))
+        if os.environ.get("NUMPYWREN_AMD_QR_BATCH_MAX"):     # (experiments: up to what the library's own rule allows)
+            cap = max(1, min(int(os.environ["NUMPYWREN_AMD_QR_BATCH_MAX"]), (2 * resident) // ((m + 511) // 512)))
         if len(As) > cap:
             out = []
             for i in range(0, len(As), cap):

@@ -556,13 +556,19 @@ def _stored_tile(bigm, idx):
 TIMEOUT_CHECK_EVERY = 32     # positions of the common task sequence between two collective looks at the clock
 
 
-def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, max_inflight=64):
+def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, max_inflight=16):
     """Distributed counterpart of job_runner.lambdapack_run: every rank calls it with the same program.
 
     Transfers are posted on the transport stream at the point of the common task sequence where the tile is produced:
     the producer's sends wait (on the device) for the producing kernel only -- not for the trailing updates queued
     behind it on the compute streams -- so a panel tile leaves as soon as its trsm has finished and the consumers'
-    receives were posted long before; the panel exchange overlaps the trailing updates of the previous step."""
+    receives were posted long before; the panel exchange overlaps the trailing updates of the previous step.
+
+    max_inflight: positions of the common sequence the host may run ahead of its own device (16: each is at least one
+    kernel of 1 - 2 ms, usually a batch).  The bound is there so that the host waits HERE, where the wait is counted as
+    `host_blocked_ms`, instead of inside a HIP launch call that returns late under back-pressure: with 64 the same
+    65536^2 run booked 480 - 900 ms of such waiting as `host_walk_ms` (profiles/r05_dist_host_split.md); the run's wall
+    time is the device's either way (1375 ms with 4, 1381 with 64)."""
     if getattr(program, "block_sparse", False):
         # an owner that skips storing a zero tile would never post the send its consumers wait for
         raise NotImplementedError("lambdapack_run_distributed: block_sparse programs are not supported (every planned "
