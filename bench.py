@@ -448,7 +448,10 @@ def main():
     comm = None
     if world > 1 or os.environ.get("NUMPYWREN_AMD_FORCE_DIST"):   # the env var exercises the N > 1 code path on 1 GPU
         from numpywren_amd import dist
-        comm = dist.init_process_group()   # control: gloo; payload: RCCL over xGMI (npw_comm_*), one process per GPU
+        # control: gloo; payload: RCCL over xGMI (npw_comm_*), one process per GPU.  The communicator itself is only made
+        # after rank 0's one-GPU anchor run (below): a live communicator makes the library leave compute units to its
+        # transfer kernels, which the anchor -- the plain one-GPU executor with its chain partition -- must not pay for
+        comm = dist.init_process_group(open_transport=False)
     be = get_backend()
     b = args.tile
     from numpywren_amd import config as npw_config
@@ -481,6 +484,8 @@ def main():
                 if hasattr(be, "trim"):
                     be.trim()
             comm.barrier()
+        if comm is not None:
+            comm.open_transport()
         X = build_input(be, nb, b, f"bench_chol_{n}_{b}", rank, world, owner)
         # inside the timed region only the roofline kernel is bracketed with events (an event record costs ~4 us of
         # stream time); the other kinds are timed in two extra steps after it, for `kernel_ms`
@@ -559,6 +564,8 @@ def main():
         # without touching the host tier (1.73 s; 7.9 s through it in round 3).  On one GPU the line carries the R-ONLY run
         # (executor.drop_unread_outputs: V / T, which no task reads, are neither assembled nor stored) beside it, as
         # `config.r_only`, never instead of it.  --r-only makes it the timed run (and says so in the workload string).
+        if comm is not None:
+            comm.open_transport()
         leaves = args.leaves or 256
         m = leaves * b
         r_only = args.r_only
@@ -596,6 +603,7 @@ def main():
         n = nb * b
         if comm is not None:
             from numpywren_amd import dist
+            comm.open_transport()
             comm.ownership = dist.gemm_ownership(world)
         A = BigMatrix(f"bench_gA_{n}", shape=(n, n), shard_sizes=(b, b), dtype=np.float32)
         B = BigMatrix(f"bench_gB_{n}", shape=(n, n), shard_sizes=(b, b), dtype=np.float32)

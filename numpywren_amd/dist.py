@@ -275,6 +275,13 @@ class Comm(object):
         self.transfers = 0
         self.headers = 0     # tiles whose (shape, dtype) had to travel over the control group
 
+    def open_transport(self):
+        """Make the payload transport now (init_process_group(open_transport=False)); every rank calls it at the same point."""
+        if self.transport is None:
+            self.transport = self._make_transport()
+            self.backend = self.transport.name
+        return self
+
     # ---- ownership ----
     def owner(self, matrix_name, idx):
         if self.ownership is not None:
@@ -305,8 +312,9 @@ class Comm(object):
         return float(t.item())
 
     def shutdown(self):
-        self.flush()
-        self.transport.close()
+        if self.transport is not None:
+            self.flush()
+            self.transport.close()
         try:
             if self.dist.is_initialized():
                 self.dist.destroy_process_group()
@@ -368,8 +376,13 @@ class Comm(object):
         return tile
 
 
-def init_process_group(backend=None):
+def init_process_group(backend=None, open_transport=True):
     """Join the job described by the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
+
+    open_transport=False: only the control group and the decision which payload transport to use; the transport itself (the
+    RCCL communicator) is made by `comm.open_transport()` -- collectively, later.  bench.py times rank 0's one-GPU anchor in
+    between: while a communicator is live the library leaves compute units to its transfer kernels, which a one-GPU run
+    beside an idle communicator would pay for nothing.
 
     The control group is torch.distributed over gloo (host side: rendezvous, barriers, a few scalars).  The PAYLOAD
     transport is libnpw_hip.so's RCCL layer (`npw_comm_*`, one communicator per rank on its own GPU) unless
@@ -416,8 +429,11 @@ def init_process_group(backend=None):
             import warnings
             warnings.warn("numpywren_amd.dist: ranks share a GPU (PCI bus ids {0}): tiles are staged through host memory "
                           "over the gloo control group, not sent over RCCL / xGMI".format(ids))
-    transport = (RcclTransport if use_rccl else HostTransport)(rank, world, dist)
-    return Comm(rank, world, transport, dist)
+    make = lambda: (RcclTransport if use_rccl else HostTransport)(rank, world, dist)
+    comm = Comm(rank, world, make() if open_transport else None, dist)
+    comm._make_transport = make
+    comm.backend = "rccl" if use_rccl else "host"
+    return comm
 
 
 # ------------------------------------------------------------------------------------------------

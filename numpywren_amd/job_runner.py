@@ -386,7 +386,13 @@ class LambdaPackExecutor(object):
         try:
             m, idx = task.reads[0]
             s0, e0 = self.compiled.matrices[m].__block_idx_to_real_idx__(idx)[0]
-            if need(self.be, int(e0 - s0)) > self.chain_cus:
+            offered = self.chain_cus
+            if not self.dry and hasattr(self.be, "stream_cus"):
+                # what the chain stream really offers a resident-grid kernel: fewer than its mask while an RCCL
+                # communicator is live in this process (compute units are left to its transfer kernels, npw_hip.h) --
+                # the factorisation then runs on the full stream instead of failing on the partition
+                offered = self.be.stream_cus(self.be.chain_streams(self.chain_cus)[0])[1]
+            if need(self.be, int(e0 - s0)) > offered:
                 return []
         except Exception:
             return []
