@@ -385,7 +385,10 @@ class LambdaPackExecutor(object):
         task = self.compiled.task(expr_idx, var_values)
         try:
             m, idx = task.reads[0]
-            s0, e0 = self.compiled.matrices[m].__block_idx_to_real_idx__(idx)[0]
+            # rows of the tile: the second to last axis (the Cholesky program's S[version, j, k] has its version axis first --
+            # axis 0 made every diagonal tile but the first look one row tall, and the check below always passed)
+            ranges = self.compiled.matrices[m].__block_idx_to_real_idx__(idx)
+            s0, e0 = ranges[-2] if len(ranges) >= 2 else ranges[0]
             offered = self.chain_cus
             if not self.dry and hasattr(self.be, "stream_cus"):
                 # what the chain stream really offers a resident-grid kernel: fewer than its mask while an RCCL

@@ -144,3 +144,53 @@ def test_resident_grid_kernels_beside_rccl_transfers():
         be.synchronize()
         _ffi.check(lib.npw_comm_destroy(h))
     assert be.stream_cus() == before                                # the reserve goes with the communicator
+
+
+def test_one_gpu_executor_beside_a_live_communicator():
+    """A plain one-GPU run (job_runner.lambdapack_run with its chain partition) in a process that holds an RCCL communicator:
+    the chain stream's 64 CUs no longer guarantee the panel chain its residency (CUs are left to transfer kernels), so the
+    executor keeps the factorisations on the full stream instead of letting npw_dpotrf_lower refuse the partition -- same
+    factor bit for bit as without a communicator."""
+    from numpywren_amd import _ffi, alg_wrappers, job_runner, matrix
+    from numpywren_amd import lambdapack as lp
+    from numpywren_amd.device import get_backend
+    from numpywren_amd.matrix import BigMatrix
+    os.environ.pop("NUMPYWREN_AMD_STORE", None)
+    matrix.OBJECTS.clear()
+    be = get_backend()
+    lib = be.lib
+    rng = np.random.default_rng(12)
+    n, b = 8192, 2048
+    G = rng.standard_normal((n, 64))
+    A = G @ G.T + n * np.eye(n)
+
+    def run(key):
+        X = BigMatrix(key, shape=(n, n), shard_sizes=(b, b), write_header=True)
+        for i in range(n // b):
+            for j in range(i + 1):
+                X.put_block(A[i * b:(i + 1) * b, j * b:(j + 1) * b], i, j)
+        program, meta = alg_wrappers.cholesky(X)
+        program.start()
+        res = job_runner.lambdapack_run(program, pipeline_width=1)
+        program.wait()
+        assert program.program_status() == lp.PS.SUCCESS, program.exceptions
+        L = meta["outputs"][0].numpy()
+        program.free()
+        X.free()
+        return L
+
+    L0 = run("comm_live_off")
+    ident = ctypes.create_string_buffer(_ffi.NPW_COMM_ID_BYTES)
+    _ffi.check(lib.npw_comm_unique_id(ident, _ffi.NPW_COMM_ID_BYTES), "unique_id")
+    h = ctypes.c_void_p(0)
+    _ffi.check(lib.npw_comm_init(ctypes.byref(h), 0, 1, ident), "comm_init")
+    try:
+        chain = be.chain_streams(64)[0]
+        assert be.stream_cus(chain) == (64, 1)          # the partition's mask, and what it guarantees now
+        L1 = run("comm_live_on")
+    finally:
+        be.synchronize()
+        _ffi.check(lib.npw_comm_destroy(h))
+    assert np.array_equal(L0, L1)
+    np.testing.assert_allclose(np.tril(L1), np.linalg.cholesky(A), rtol=1e-10, atol=1e-9)
+    matrix.OBJECTS.clear()
