@@ -35,7 +35,12 @@ def _worker(rank, world, port, scenario, outdir):
     from oracle_backend import OracleBackend
 
     device.set_backend(OracleBackend())
-    comm = dist.init_process_group("gloo")
+    # (the two-phase form bench.py uses: control group first, the payload transport -- collectively -- later)
+    comm = dist.init_process_group("gloo", open_transport=False)
+    assert comm.transport is None and comm.backend == "host"
+    comm.barrier()
+    comm.open_transport()
+    assert comm.transport is not None and comm.backend == "host" and comm.open_transport() is comm
     ALG = np.load(os.path.join(GOLDEN, "algos.npz"))
     result = {}
 
