@@ -458,7 +458,9 @@ def main():
     chain_cus = int(npw_config.default()["executor"].get("chain_cus", 0) or 0) if (world == 1 and args.streams == 1) else 0
     run = Runner(be, comm, args.streams, args.priority_stream)
     anchor = None
-    par = "1 gpu" if world == 1 else f"{world} gpus, one process each, tiles 2-D block-cyclic, RCCL p2p panel exchange (npw_comm_*)"
+    par = "1 gpu" if world == 1 else (f"{world} gpus, one process each, tiles 2-D block-cyclic, " + (
+        "RCCL p2p panel exchange (npw_comm_*)" if comm is not None and comm.backend == "rccl" else
+        "payloads staged through the host over the control group (ranks share a GPU: not a production transport)"))
 
     if args.workload == "chol":
         # N = 1: configs[1] (16384^2).  N > 1: STRONG scaling of configs[2]'s 65536^2 matrix (it fits one GPU: 34 GB).
