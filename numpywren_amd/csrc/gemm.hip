@@ -872,6 +872,17 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
         p.tiles_n = (int)ceil_div(n, 128);
         const bool full = vec_ok && k_ok && (m % 128 == 0) && (n % 128 == 0);
         NPW_REQUIRE(full || opts.tag != 2, "gemm: the symmetric (tag 2) product needs full, aligned 128 x 128 tiles");
+        if constexpr (sizeof(T) == 4) {
+            // fp32, both operands k-contiguous: k-tiles of 32 (the same 128 bytes per row as fp64's 16) -- a k-tile of 16 floats
+            // holds half the matrix-pipe time of the fp64 one behind the same barrier.  Measured (tools/sgemm_time.py, 4096^3):
+            // N / T 140.4 -> 141.5 TFLOP/s; the other three forms LOSE 3.5 % with it (134 -> 129) and keep 16.
+            // $NPW_SGEMM_BK32=0 restores 16 everywhere for A/B runs.
+            static const bool bk32 = [] {
+                const char* e = getenv("NPW_SGEMM_BK32");
+                return e == nullptr || atoi(e) != 0;
+            }();
+            if (bk32 && full && a_kc && b_kc && k % 32 == 0 && opts.k_chunk_ % 32 == 0) return launch<T, 128, 128, 32, true, true, false>(p, stream);
+        }
         if (full) return dispatch_layout<T, 128, 128, BK, false>(a_kc, b_kc, p, stream);
         return dispatch_layout<T, 128, 128, BK, true>(a_kc, b_kc, p, stream);
     }
