@@ -754,7 +754,8 @@ class HipBackend(object):
         """Start an asynchronous copy of `tile` into pinned host memory (after its producer) and return the
         SpilledTile that stands for it.  The device buffer goes back to the pool once every holder has dropped
         the tile and the copy has left the spill stream."""
-        kept = tile.buf.aux.get("host_copy") if (isinstance(tile.buf.aux, dict) and tile.offset == 0) else None
+        # (host copies are kept per byte offset into the buffer: the outputs of a batched kernel share one allocation)
+        kept = (tile.buf.aux.get("host_copies") or {}).get(tile.offset) if isinstance(tile.buf.aux, dict) else None
         if kept is not None and kept.nbytes == tile.nbytes and kept.dtype == tile.dtype:
             return kept if kept.shape == tile.shape else SpilledTile(kept.buf, tile.shape, tile.dtype, kept.ready)
         sp = self.spill_stream()
@@ -770,7 +771,7 @@ class HipBackend(object):
     def restore_from_host(self, spilled):
         """A new DeviceTile with the contents of `spilled`, copied on the inbound spill stream behind the D2H that
         filled the host buffer; consumers wait for the tile's `ready` event as for any producer.  The tile remembers
-        its host copy (`buf.aux["host_copy"]`): stored tiles are immutable, so pushing it out again costs no copy."""
+        its host copy (`buf.aux["host_copies"][offset]`): stored tiles are immutable, so pushing it out again costs no copy."""
         sp = self.spill_stream(inbound=True)
         t = self.empty(spilled.shape, spilled.dtype)
         if spilled.ready is not None:
@@ -779,7 +780,7 @@ class HipBackend(object):
             _ffi.check(self.lib.npw_memcpy_h2d_async(t.ptr, spilled.buf.ptr, t.nbytes, sp.handle), "restore h2d")
         self._produced(sp, t)
         spilled.buf.streams.add(sp.handle)
-        t.buf.aux = {"host_copy": spilled}
+        t.buf.aux = {"host_copies": {0: spilled}}
         with self._lock:
             self.restored_bytes_total += t.nbytes
         return t

@@ -197,12 +197,13 @@ class Residency(object):
         32768^2 with 12 tiles of budget: the copies in and out took turns instead of overlapping, tools/spill_timeline.py).
         In production order the copies out run in the order the copies back will be asked for."""
         plan, budget = self.plan, self.budget
-        if plan is None or budget is None or not self._evictable(obj) or getattr(obj, "offset", 0) != 0:
+        if plan is None or budget is None or not self._evictable(obj):
             return False
         if not hasattr(obj.buf, "aux") or not hasattr(be, "spill_to_host"):
             return False        # (a backend whose buffers carry no host copies: pushing out later copies)
         aux = obj.buf.aux
-        if isinstance(aux, dict) and aux.get("host_copy") is not None:
+        offset = getattr(obj, "offset", 0)   # (a batched kernel's outputs share one allocation: one host copy per tile of it)
+        if isinstance(aux, dict) and (aux.get("host_copies") or {}).get(offset) is not None:
             return False
         mine = plan.next_use(tkey)
         sooner = obj.nbytes
@@ -216,7 +217,10 @@ class Residency(object):
         if sooner <= budget:
             return False
         sp = be.spill_to_host(obj)
-        obj.buf.aux = dict(aux or {}, host_copy=sp)
+        aux = dict(aux or {})
+        aux["host_copies"] = dict(aux.get("host_copies") or {})
+        aux["host_copies"][offset] = sp
+        obj.buf.aux = aux
         self.written_through += 1
         return True
 
