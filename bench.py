@@ -297,7 +297,7 @@ class Runner(object):
                 be = self.be
                 print(f"[bench] allocated {be.allocated_bytes / 2**30:.1f} GiB, pooled {be.pooled_bytes / 2**30:.1f}, peak "
                       f"{be.peak_bytes / 2**30:.1f}, spilled {be.spilled_bytes_total / 2**30:.1f}, restored "
-                      f"{be.restored_bytes_total / 2**30:.1f}", file=sys.stderr)
+                      f"{be.restored_bytes_total / 2**30:.1f}, allocator syncs {getattr(be, 'alloc_syncs', 0)}", file=sys.stderr)
                 print("        pool: " + ", ".join(f"{k / 2**20:.0f}MiB x{len(v)}" for k, v in sorted(be._free.items()) if v and k >= 2**26),
                       "| pending:", len(be._pending), file=sys.stderr)
         else:

@@ -250,6 +250,9 @@ class HipBackend(object):
         # the pool's own ceiling (see _alloc_raw): a little below the device's memory, which other allocations (RCCL,
         # the runtime's code objects and queues) share.  $NUMPYWREN_AMD_ALLOC_LIMIT (bytes) overrides; 0 = none.
         self.alloc_limit_bytes = int(os.environ.get("NUMPYWREN_AMD_ALLOC_LIMIT", int(0.94 * mem.value)))
+        self.alloc_syncs = 0                              # device-wide synchronisations the allocator had to take at its ceiling
+        self._small_alloc = 16 << 20                      # blocks up to this size may use ...
+        self._small_slack = int(0.01 * mem.value)         # ... this much beyond the ceiling (see _alloc_raw)
         self.compute_units = cus.value
         self.clock_khz = khz.value
         self._lock = threading.RLock()
@@ -520,6 +523,12 @@ class HipBackend(object):
             # are still running -- a pipelining caller releases step i's tiles while step i + 1 is already queued on
             # the same streams -- and (2) hand cached blocks of other sizes back to the driver.
             limit = self.alloc_limit_bytes
+            if limit and nbytes <= self._small_alloc and self.allocated_bytes + nbytes <= limit + self._small_slack:
+                # a small block (flags, info words, a tile header's worth) at the ceiling: the ceiling sits 6 % below the
+                # device's memory precisely so that such a request need not take the path below -- a device-wide
+                # synchronise per missed 256-byte block drained the whole pipeline of a run that lives at the ceiling
+                # (the 256-leaf TSQR under a 96 GiB budget: the copy stream was busy 60 % of a step)
+                limit = 0
             if limit and self.allocated_bytes + nbytes > limit:
                 for events, bufs in self._pending:
                     for idx, (ptr, nb, streams) in enumerate(bufs):
@@ -535,6 +544,7 @@ class HipBackend(object):
         if rc != 0:
             # out of memory: give everything cached back to the driver and retry; then let the store push
             # least-recently-used tiles out to pinned host memory and retry once more
+            self.alloc_syncs += 1
             self.synchronize()
             self.trim()
             over = bool(limit) and self.allocated_bytes + nbytes > limit
