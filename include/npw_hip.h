@@ -44,6 +44,14 @@ typedef void* npw_event_t;  /* hipEvent_t  */
 
 /* ---- library / device management ------------------------------------------ */
 int npw_version(void);
+
+/* Named ranges for profilers (roctx, loaded on first use: librocprofiler-sdk-roctx / libroctx64; without either the calls
+ * succeed and do nothing): the executor brackets the kernels it enqueues for one task with a range "<kernel>(<node>)" when
+ * executor.roctx_ranges is on, so that `rocprofv3 --marker-trace` shows tasks beside kernels -- the counterpart of the
+ * reference's per-instruction start_time / end_time records (numpywren/lambdapack.py:210-211, 361, 379).  Host-side ranges:
+ * they mark when a task's work was ENQUEUED.  npw_range_push returns the nesting depth (>= 0) or a negative error. */
+int npw_range_push(const char* name);
+int npw_range_pop(void);
 /* thread-local message of the last failing call on this thread ("" if none) */
 const char* npw_last_error(void);
 int npw_device_count(int* count);

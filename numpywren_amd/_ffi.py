@@ -28,6 +28,8 @@ NPW_ERR_UNSUPPORTED = -4
 _vp, _i64, _sz = c_void_p, c_int64, c_size_t
 PROTOTYPES = {
     "npw_version": (c_int, []),
+    "npw_range_push": (c_int, [c_char_p]),
+    "npw_range_pop": (c_int, []),
     "npw_last_error": (c_char_p, []),
     "npw_device_count": (c_int, [POINTER(c_int)]),
     "npw_set_device": (c_int, [c_int]),

@@ -39,6 +39,9 @@ DEFAULTS = {
         # THROUGHPUT kernels (syrk, trsm, gemm) are at most `spill_batch_tasks` tasks: a batched launch waits for the
         # copy-in of ALL its operands, so 16 trailing updates per launch make copies and kernels take turns (32768^2
         # Cholesky, 12 tiles of budget: 404 ms with batches of 32, 328 with 8; 24 tiles: 264 / 204 with 4).
+        # One roctx range per task / batch ("<kernel>(<node>)") around the calls that enqueue its kernels (npw_range_push / _pop):
+        # `rocprofv3 --marker-trace` shows tasks beside kernels.  Off: two library calls per task.
+        "roctx_ranges": False,
         "spill_plan": True,
         "spill_prefetch_tasks": 2,
         "spill_batch_tasks": 8,

@@ -25,6 +25,7 @@ int set_error(int code, const char* fmt, ...) {
 
 using npw::as_stream;
 
+#include <dlfcn.h>
 #include <cstdlib>
 #include <map>
 #include <atomic>
@@ -196,6 +197,43 @@ int stream_cu_count_query(hipStream_t s) {
 extern "C" {
 
 int npw_version(void) { return 100; }
+
+namespace {
+struct Roctx {
+    bool tried = false;
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+Roctx g_roctx;
+std::mutex g_roctx_mutex;
+void load_roctx() {
+    std::lock_guard<std::mutex> lock(g_roctx_mutex);
+    if (g_roctx.tried) return;
+    g_roctx.tried = true;
+    for (const char* n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+        void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h == nullptr) continue;
+        auto push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        auto pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (push != nullptr && pop != nullptr) {
+            g_roctx.push = push;
+            g_roctx.pop = pop;
+            return;
+        }
+    }
+}
+}  // namespace
+
+int npw_range_push(const char* name) {
+    NPW_REQUIRE(name != nullptr, "npw_range_push: NULL name");
+    if (!g_roctx.tried) load_roctx();
+    return g_roctx.push != nullptr ? g_roctx.push(name) : 0;
+}
+
+int npw_range_pop(void) {
+    if (!g_roctx.tried) load_roctx();
+    return g_roctx.pop != nullptr ? g_roctx.pop() : 0;
+}
 
 const char* npw_last_error(void) { return npw::error_buffer(); }
 

@@ -195,6 +195,10 @@ class LambdaPackExecutor(object):
         # diagnostics (off by default: two event records per task cost ~8 us of stream time): every task's kernels are
         # bracketed with timing events on their stream; collect_task_times() adds them up by kernel name
         self.task_timers = bool(cfg.get("task_timers", False)) and hasattr(self.be, "new_event")
+        # profiler ranges (roctx through the C-ABI's npw_range_push / _pop): one host-side range per task or batch, named
+        # "<kernel>(<node>)", around the calls that enqueue its kernels -- `rocprofv3 --marker-trace` then shows tasks beside
+        # kernels.  The counterpart of the reference's per-instruction start / end records (lambdapack.py:210-211, 361, 379).
+        self.roctx = bool(cfg.get("roctx_ranges", False)) and hasattr(self.be, "lib") and hasattr(self.be.lib, "npw_range_push")
         self._task_times = program.__dict__.setdefault("_task_times", [])
         pool = getattr(self.be, "bulk_streams", None) or self.be.streams
         n = max(1, min(int(pipeline_width), len(pool)))
@@ -284,6 +288,25 @@ class LambdaPackExecutor(object):
         res = matrix.RESIDENCY
         if self.prefetch_tasks and res.evictions and res.plan is plan:
             res.prefetch(self.be, self.prefetch_tasks)
+
+    def _range(self, compute, nodes):
+        """Context manager: a named profiler range around the enqueue of `nodes` (no-op unless executor.roctx_ranges)."""
+        import contextlib
+        if not self.roctx:
+            return contextlib.nullcontext()
+        lib = self.be.lib
+        e, v = nodes[0]
+        name = "{0}({1}{2})".format(getattr(compute, "__name__", "task"), self.program._node_str(e, v),
+                                    "" if len(nodes) == 1 else " +%d" % (len(nodes) - 1))
+
+        @contextlib.contextmanager
+        def scope():
+            lib.npw_range_push(name.encode())
+            try:
+                yield
+            finally:
+                lib.npw_range_pop()
+        return scope()
 
     # ---- per-task device timing (executor.task_timers) ----
     def _tic(self, stream):
@@ -506,7 +529,8 @@ class LambdaPackExecutor(object):
         if device_kernel:
             args = [tiles[j] if kind == "tile" else task.consts[j] for kind, j in task.arg_kinds]
             tic = self._tic(stream)
-            with kernels.stream_scope(stream, self.program.info_flags_sink(task), self.exact_zero, self._unwanted([task])):
+            with self._range(compute, [(expr_idx, var_values)]), \
+                    kernels.stream_scope(stream, self.program.info_flags_sink(task), self.exact_zero, self._unwanted([task])):
                 results = compute(*args, **task.kwargs)
             self._toc(getattr(compute, "__name__", "kernel"), stream, tic)
         else:
@@ -588,7 +612,8 @@ class LambdaPackExecutor(object):
         self._issued(tasks)
         others = self._fence_in(compute, stream)
         tic = self._tic(stream)
-        with kernels.stream_scope(stream, self.program.info_flags_sink(tasks[0]), self.exact_zero, self._unwanted(tasks)):
+        with self._range(compute, nodes), \
+                kernels.stream_scope(stream, self.program.info_flags_sink(tasks[0]), self.exact_zero, self._unwanted(tasks)):
             results = compute._npw_batch(self.be, stream, arg_lists, kwargs_list)
         self._toc(getattr(compute, "__name__", "kernel"), stream, tic, len(tasks))
         self._fence_out(others, stream)

@@ -367,3 +367,21 @@ def test_tsqr_batched_tasks_match_one_by_one(hbm_store):
         np.testing.assert_allclose(a, c, atol=1e-12, rtol=0)
     R = res[8][0]
     np.testing.assert_allclose(R.T @ R, Xh.T @ Xh, atol=1e-10 * np.linalg.norm(Xh) ** 2)
+
+
+def test_roctx_ranges_option_runs(hbm_store):
+    """executor.roctx_ranges: every task's enqueue is bracketed with a named profiler range (npw_range_push / _pop); the run is
+    the same run (rocprofv3 --marker-trace output of such a run: profiles/r05_roctx_ranges.txt)."""
+    rng = np.random.default_rng(31)
+    n, b = 1024, 256
+    G = rng.standard_normal((n, n))
+    A = G @ G.T + n * np.eye(n)
+    X = BigMatrix("roctx_chol", shape=A.shape, shard_sizes=(b, b), write_header=True)
+    shard_matrix(X, A)
+    program, meta = alg_wrappers.cholesky(X)
+    program.config["executor"]["roctx_ranges"] = True
+    program.start()
+    job_runner.lambdapack_run(program, timeout=120)
+    program.wait()
+    assert program.program_status() == lp.PS.SUCCESS, program.exceptions
+    np.testing.assert_allclose(np.tril(meta["outputs"][0].numpy()), np.linalg.cholesky(A), rtol=1e-10, atol=1e-9)

@@ -44,6 +44,10 @@ def test_version_and_error_string():
     # compute units the panel chain of an n x n factorisation has to be resident on (one workgroup per 64 rows below
     # the 128-wide diagonal block, + 1): what a CU-masked stream must offer
     assert [lib.npw_dpotrf_lower_resident_cus(n) for n in (0, 100, 128, 129, 1024, 4096, 8192)] == [0, 1, 1, 2, 15, 63, 127]
+    # profiler ranges (roctx, loaded on demand; without a profiler attached they cost a call): push returns the nesting depth
+    d0 = lib.npw_range_push(b"outer")
+    d1 = lib.npw_range_push(b"inner")
+    assert d0 >= 0 and d1 >= d0 and lib.npw_range_pop() >= 0 and lib.npw_range_pop() >= 0
 
 
 def test_no_cpu_fallback():
