@@ -344,6 +344,8 @@ class LambdaPackExecutor(object):
                         if self.drop_unread else set())
         for t in self.compiled.tasks:
             local = self.is_local is None or self.is_local(t)
+            if local and self.program.get_node_status(t.expr_idx, t.vars) == lp.NS.FINISHED:
+                continue        # (a resumed run -- LambdaPackProgram.resume: this reader has had its turn)
             if local:
                 for r in set(t.reads):
                     if r[0] not in keep and self.compiled.writer_of(*r) is not None:

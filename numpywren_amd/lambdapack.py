@@ -433,6 +433,35 @@ class LambdaPackProgram(object):
             self.return_success()
         return 0
 
+    def resume(self, finished):
+        """A fresh run state in which the tasks `finished` ([(expr_idx, var_values)]: e.g. checkpoint.finished_nodes of an
+        interrupted run whose tiles are back in the store) count as done: start(), then their dependency accounting is
+        replayed -- each one is taken off the ready heap and post_op'ed, which releases its children -- without running them.
+        What is left on the heap is what lambdapack_run continues with.  (In the reference this state IS durable -- Redis
+        edge counters, lambdapack.py:545-639 -- and nothing has to be replayed.)"""
+        from .compiler import node_key
+        done = {node_key(e, v) for e, v in finished}
+        self.start()
+        held, replayed = [], 0
+        while True:
+            node = self.dequeue()
+            if node is None:
+                break
+            e, v = node
+            if node_key(e, v) in done:
+                self.set_node_status(e, v, NS.RUNNING)
+                self.post_op(e, v, PS.SUCCESS, None)
+                self.set_node_status(e, v, NS.FINISHED)
+                replayed += 1
+            else:
+                held.append(node)
+        for node in held:
+            self._enqueue(node)
+        if replayed != len(done):
+            raise ValueError("resume: {0} of the {1} finished tasks are not reachable through finished parents".format(
+                len(done) - replayed, len(done)))
+        return replayed
+
     def post_op(self, expr_idx, var_values, ret_code, inst_block, tb=None):
         """Dependency accounting after a task: mark its out-edges, enqueue children whose parents
         are all done, count terminators (reference lambdapack.py:545-639)."""
