@@ -1,0 +1,7 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+O=gpurun_out/r05final; mkdir -p $O
+timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -3 $O/pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; python -c "
+import json; d=json.load(open('$O/bench.json')); print(d['value'], d['ms_per_step'], d['step_ms'], d['roofline']['frac'], d['north_star']['tflops'], d['cpu_baseline']['value'])"
