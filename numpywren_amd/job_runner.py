@@ -232,7 +232,9 @@ class LambdaPackExecutor(object):
         if hasattr(self.be, "restore_from_host"):
             from . import matrix
             res = matrix.RESIDENCY
-            tier_at_work = matrix._store_tier() != "host" and (res.budget is not None or res.evictions > 0)
+            # "at work": a byte budget is set, or tiles of THIS program's matrices sit in host memory right now (an earlier
+            # eviction somewhere in the process's past does not make every later, fully resident run pay for small batches)
+            tier_at_work = matrix._store_tier() != "host" and (res.budget is not None or self._has_spilled_tiles())
             if tier_at_work:
                 # (also in the dry walk: the plan must see the batches the real run forms)
                 self.spill_batch = max(1, int(cfg.get("spill_batch_tasks", 8)))
@@ -244,6 +246,14 @@ class LambdaPackExecutor(object):
                     # only made if the allocator's out-of-memory handler asks the tier for memory during this run
                     res.plan = None
                     res.plan_factory = self._install_spill_plan
+
+    def _has_spilled_tiles(self):
+        from .device import SpilledTile
+        for m in getattr(self.compiled, "matrices", {}).values():
+            tiles = m._tiles(False) if hasattr(m, "_tiles") else None
+            if tiles and any(isinstance(t, SpilledTile) for t in list(tiles.values())):
+                return True
+        return False
 
     def _install_spill_plan(self):
         from . import matrix
@@ -286,7 +296,7 @@ class LambdaPackExecutor(object):
         for t in tasks:
             plan.issued(t.index)
         res = matrix.RESIDENCY
-        if self.prefetch_tasks and res.evictions and res.plan is plan:
+        if self.prefetch_tasks and res.evictions and res.plan is plan:   # (nothing ever pushed out: nothing to bring back)
             res.prefetch(self.be, self.prefetch_tasks)
 
     def _range(self, compute, nodes):
