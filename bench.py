@@ -392,6 +392,25 @@ def cholesky_residual(be, X, O, nb, full=False):
     return float(np.sqrt(num / den))
 
 
+def one_gpu_anchor(be, comm, rank, what, make_input, build, flops, r_only=False):
+    """N > 1 lines: the SAME problem on one GPU of this box -- rank 0 alone with the plain one-GPU executor, before the
+    communicator exists (the other ranks wait at the barrier) -- so that a scaling curve has its own measured N = 1 point."""
+    anchor = None
+    if rank == 0:
+        solo = Runner(be, None, 1, r_only=r_only)
+        mats = make_input()
+        ea, ma = solo.timed(lambda: build(*mats), 2, 1)
+        anchor = {"what": what + " on one GPU (rank 0, before the timed multi-GPU steps)", "steps": 2,
+                  "ms_per_step": round(ea / 2 * 1e3, 3), "tflops": round(2 * flops / ea / 1e12, 3), "step_ms": solo.step_ms}
+        for m_ in list(mats) + ma["outputs"] + ma["intermediates"]:
+            m_.free()
+        del mats, ma, solo
+        if hasattr(be, "trim"):
+            be.trim()
+    comm.barrier()
+    return anchor
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -410,7 +429,7 @@ def main():
     ap.add_argument("--r-only", action="store_true", help="tsqr: the timed run drops the V / T factors (no task reads them) instead of producing them")
     ap.add_argument("--keep-vt", action="store_true", help="tsqr: (the default since round 4; kept for old command lines)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 65536^2 single-GPU run of the N = 1 line")
-    ap.add_argument("--no-anchor", action="store_true", help="N > 1 chol: skip rank 0's one-GPU run of the same matrix (config.one_gpu_anchor)")
+    ap.add_argument("--no-anchor", action="store_true", help="N > 1: skip rank 0's one-GPU run of the same problem (config.one_gpu_anchor)")
     ap.add_argument("--dry-run", action="store_true", help="start / join the ranks, print who joined as one JSON line, do no GPU work")
     args = ap.parse_args()
 
@@ -472,20 +491,9 @@ def main():
             # one-GPU executor; the other ranks wait at the barrier) -- the N = 1 bench line's `value` is configs[1]'s
             # 16384^2 matrix, another problem, so a curve must be built from these anchors (or from that line's
             # `north_star`), never from its `value`.
-            if rank == 0:
-                solo = Runner(be, None, 1)
-                Xa = build_input(be, nb, b, f"bench_chol_anchor_{n}_{b}")
-                ea, ma = solo.timed(lambda: alg_wrappers.cholesky(Xa), 2, 1)
-                anchor = {"what": f"the same {n}x{n} matrix on one GPU (rank 0, before the timed multi-GPU steps)", "steps": 2,
-                          "ms_per_step": round(ea / 2 * 1e3, 3), "tflops": round(2 * (n ** 3 / 3.0) / ea / 1e12, 3),
-                          "step_ms": solo.step_ms}
-                Xa.free()
-                for m_ in ma["outputs"] + ma["intermediates"]:
-                    m_.free()
-                del Xa, ma, solo
-                if hasattr(be, "trim"):
-                    be.trim()
-            comm.barrier()
+            anchor = one_gpu_anchor(be, comm, rank, f"the same {n}x{n} matrix",
+                                    lambda: (build_input(be, nb, b, f"bench_chol_anchor_{n}_{b}"),),
+                                    lambda Xa: alg_wrappers.cholesky(Xa), n ** 3 / 3.0)
         if comm is not None:
             comm.open_transport()
         X = build_input(be, nb, b, f"bench_chol_{n}_{b}", rank, world, owner)
@@ -566,12 +574,21 @@ def main():
         # without touching the host tier (1.73 s; 7.9 s through it in round 3).  On one GPU the line carries the R-ONLY run
         # (executor.drop_unread_outputs: V / T, which no task reads, are neither assembled nor stored) beside it, as
         # `config.r_only`, never instead of it.  --r-only makes it the timed run (and says so in the workload string).
-        if comm is not None:
-            comm.open_transport()
         leaves = args.leaves or 256
         m = leaves * b
         r_only = args.r_only
         run.r_only = r_only
+        if world > 1 and not args.no_anchor:
+            def all_leaves():
+                Xa = BigMatrix(f"bench_tsqr_anchor_{m}", shape=(m, b), shard_sizes=(b, b))
+                for j in range(leaves):
+                    Xa.put_tile(be.fill_random((b, b), 7, j * b, 0), j, 0)
+                be.synchronize()
+                return (Xa,)
+            anchor = one_gpu_anchor(be, comm, rank, f"the same {m}x{b} TSQR" + (" (R only)" if r_only else " (R, V, T)"), all_leaves,
+                                    lambda Xa: alg_wrappers.tsqr(Xa), 2.0 * m * b * b - 2.0 * b ** 3 / 3, r_only=r_only)
+        if comm is not None:
+            comm.open_transport()
         if comm is not None:
             from numpywren_amd import dist
             comm.ownership = dist.tsqr_ownership(world, leaves)
@@ -603,6 +620,18 @@ def main():
         # configs[4]: 32768^2 fp32 GEMM program (fp32 MFMA products, the reference's fp64 add_matrices tree), strong scaling
         nb = args.tiles or 8
         n = nb * b
+        if world > 1 and not args.no_anchor:
+            def all_tiles():
+                Aa = BigMatrix(f"bench_gA_anchor_{n}", shape=(n, n), shard_sizes=(b, b), dtype=np.float32)
+                Ba = BigMatrix(f"bench_gB_anchor_{n}", shape=(n, n), shard_sizes=(b, b), dtype=np.float32)
+                for i in range(nb):
+                    for j in range(nb):
+                        Aa.put_tile(be.convert(be.fill_random((b, b), 11, i * b, j * b), np.float32), i, j)
+                        Ba.put_tile(be.convert(be.fill_random((b, b), 12, i * b, j * b), np.float32), i, j)
+                be.synchronize()
+                return (Aa, Ba)
+            anchor = one_gpu_anchor(be, comm, rank, f"the same {n}x{n} fp32 GEMM program", all_tiles,
+                                    lambda Aa, Ba: alg_wrappers.gemm(Aa, Ba), 2.0 * n ** 3)
         if comm is not None:
             from numpywren_amd import dist
             comm.open_transport()

@@ -128,6 +128,9 @@ def test_bench_two_ranks_on_one_gpu(workload, extra, port):
             assert key in t and key in x, key
         assert x["kernel_busy_ms"] > 0 and x["kernel_ms_by_name"] and x["transfer_wait_ms"] >= 0 and x["step_ms"] > 0
     assert line["config"]["predicted"]["tflops_by_gpus"]["8"] > 0 and "not a measurement" in line["config"]["predicted"]["source"]
+    # every N > 1 line carries its own measured N = 1 point: the same problem on rank 0 alone, before the communicator exists
+    a = line["config"]["one_gpu_anchor"]
+    assert a["tflops"] > 0 and a["ms_per_step"] > 0 and len(a["step_ms"]) == 2 and "one GPU" in a["what"]
     if workload == "chol":
         assert line["scaling"] == "strong" and sum(d["timed_step"]["bytes_sent"] for d in line["per_rank"]) > 0
 
