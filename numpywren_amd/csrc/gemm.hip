@@ -119,8 +119,7 @@ struct GemmParams {
     int k_from_diag;                                  // k range of tile (m0, n0) starts at max(m0, n0) (trapezoidal operands)
     int a_upper_tri;                                  // k range of row tile m0 starts at m0 (op(A) upper triangular)
     int use_delta;                                    // irregular batch: element offsets per problem instead of strides
-    int a_lower_tri;                                  // k range of row tile m0 ends at m0 + BM (op(A) lower triangular)
-                                                      // (sixth int of the group: fills the padding before the int64 arrays)
+    int pad_;                                         // (sixth int of the group: the padding before the int64 arrays, named)
     int64_t da[16], db[16], dc[16], dd[16];
     int64_t ds0[16], ds1[16];                         // ... and of the skip flags (int32 units)
     // (at the END: nothing above moves)  tag 2: diagonal blocks in the same launch -- see GemmOpts::diag_ws
@@ -281,7 +280,6 @@ __global__ __launch_bounds__(128 * NW, 2) void gemm_kernel(const GemmParams<T> p
     if (p.a_upper_tri) kb = max(kb, (m0 / BK) * BK);           // T1 * X with T1 upper triangular: columns left of the diagonal are zero
     int kend = p.k_chunk > 0 ? min(p.K, kb + p.k_chunk) : p.K;
     if (p.b_lower_tri) kend = min(kend, n0 + BN);  // rows of W^T below the diagonal block are zero
-    if (p.a_lower_tri) kend = min(kend, m0 + BM);  // columns of op(A) right of the diagonal block are zero
     if (p.b_blockdiag > 0) {
         // W's block g = n0 / width sits at B + g width^2 with ld = width: element (n, k) of the virtual n x n matrix is at
         // B + n ld + (k - g width), and the block only has k in [g width, n0 + BN)
@@ -786,7 +784,7 @@ int gemm(char transA, char transB, int64_t m, int64_t n, int64_t k, T alpha, con
     NPW_REQUIRE(opts.a_blockdiag == 0 || (opts.b_blockdiag == 0 && !ta && opts.a_blockdiag % 128 == 0 && m % opts.a_blockdiag == 0 && k == m &&
                                           lda == opts.a_blockdiag && opts.force_big && !opts.lower_only && opts.k_chunk_ == 0 && n % 128 == 0),
                 "gemm: a_blockdiag needs op(A) = N, whole 128-column tiles, m == k a multiple of the block width, lda == width and force_big");
-    p.a_lower_tri = opts.a_lower_tri ? 1 : 0;
+    p.pad_ = 0;
     NPW_REQUIRE(opts.b_blockdiag == 0 || (tb && !ta && opts.b_blockdiag % 128 == 0 && n % opts.b_blockdiag == 0 && k == n &&
                                           ldb == opts.b_blockdiag && opts.force_big && !opts.lower_only && opts.k_chunk_ == 0 && m % 128 == 0),
                 "gemm: b_blockdiag needs op(A) = N, op(B) = T, whole 128-row tiles, n == k a multiple of the block width, ldb == width and force_big");

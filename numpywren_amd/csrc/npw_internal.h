@@ -68,7 +68,6 @@ struct GemmOpts {
     bool b_lower_tri = false;  // op(B) = W^T with W (n x k) lower triangular: column tile n0 only needs k < n0 + BN
     bool k_from_diag = false;  // op(A)^T, op(B) (k x m, k x n) lower trapezoidal: tile (m0, n0) only needs k >= max(m0, n0)
     bool a_upper_tri = false;  // op(A) (m x k) upper triangular: row tile m0 only needs k >= m0
-    bool a_lower_tri = false;  // op(A) (m x k) lower triangular: row tile m0 only needs k < m0 + BM
     // op(B) = W^T with W block diagonal: `b_blockdiag`-wide lower triangular diagonal blocks stored back to back (block g at
     // B + g * b_blockdiag^2, ldb = b_blockdiag).  Column tile n0 of block g sums over k in [g * b_blockdiag, n0 + BN).  One launch
     // over all blocks, 128 x 128 tiles handed out longest first (trsm's group products: factor.hip trsm_fused).
