@@ -21,6 +21,7 @@ class _Buf(object):
         self.ptr = 0
         self.nbytes = 0
         self.streams = set()
+        self.aux = None       # like DeviceBuffer.aux: {"host_copies": {offset: SpilledTile}} once the tile has a host copy
 
 
 class HostTile(DeviceTile):
@@ -107,12 +108,20 @@ class OracleBackend(object):
 
     # host-DRAM tier: "pinned memory" is an ndarray here, the copies are synchronous
     def spill_to_host(self, tile):
+        # (like HipBackend.spill_to_host: a tile that still has its host copy -- written through when it was stored, or kept
+        #  from an earlier restore -- leaves without a copy)
+        kept = (tile.buf.aux.get("host_copies") or {}).get(tile.offset) if isinstance(tile.buf.aux, dict) else None
+        if kept is not None and kept.nbytes == tile.nbytes and kept.dtype == tile.dtype:
+            self.calls.append(("spill_free", tile.shape))
+            return kept if kept.shape == tile.shape else SpilledTile(kept.buf, tile.shape, tile.dtype, kept.ready)
         self.calls.append(("spill", tile.shape))
         return SpilledTile(_Bytes(np.array(tile.array)), tile.shape, tile.dtype)
 
     def restore_from_host(self, spilled):
         self.calls.append(("restore", spilled.shape))
-        return HostTile(spilled.buf.array.reshape(spilled.shape))
+        t = HostTile(spilled.buf.array.reshape(spilled.shape))
+        t.buf.aux = {"host_copies": {0: spilled}}
+        return t
 
     def spilled_to_numpy(self, spilled):
         return np.array(spilled.buf.array).reshape(spilled.shape)

@@ -194,9 +194,9 @@ def test_plan_driven_eviction_moves_fewer_tiles_than_lru(oracle_backend):
     x = rng.standard_normal((n, n))
     a = x @ x.T + n * np.eye(n)
 
-    def run(key, plan):
+    def run(key, plan, budget_tiles=24):
         matrix.RESIDENCY.reset()
-        matrix.RESIDENCY.set_budget(24 * b * b * 8)
+        matrix.RESIDENCY.set_budget(budget_tiles * b * b * 8)
         A = BigMatrix(key, shape=(n, n), shard_sizes=(b, b), write_header=True)
         for i in range(nb):
             for j in range(i + 1):
@@ -219,6 +219,12 @@ def test_plan_driven_eviction_moves_fewer_tiles_than_lru(oracle_backend):
     assert lru["policy"] == "lru" and plan["policy"] == "plan"
     assert np.array_equal(L_lru, L_plan) and np.allclose(np.tril(L_plan), np.linalg.cholesky(a))
     assert plan["restores"] * 2 <= lru["restores"] and plan["evictions"] < lru["evictions"], (plan, lru)
+    # with half the budget, tiles that cannot stay until their next read are copied out as they are stored (write-through) and
+    # pushing them out later is free: the backend sees "spill_free" calls; same factor again
+    del oracle_backend.calls[:]
+    L_tight, tight = run("res_plan_tight", True, budget_tiles=12)
+    assert np.array_equal(L_tight, L_plan) and tight["written_through"] > 0
+    assert [c[0] for c in oracle_backend.calls].count("spill_free") > 0
     matrix.RESIDENCY.reset()
 
 
