@@ -159,8 +159,10 @@ int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t l
  * handed over together by the executor.  Arrays of `count` device pointers (16-byte aligned tiles; D[z] may alias
  * S[z]); skip_x / skip_y: arrays of per-problem flags or both NULL.  Every problem is computed exactly as
  * npw_dgemm_nt_sub computes it; the symmetric route (X[z] == Y[z]) is taken when ALL problems qualify -- callers batch
- * diagonal and off-diagonal tiles separately.  workspace: `count` x npw_dgemm_nt_sub_workspace_bytes(m, n, k) bytes (every
- * problem's diagonal blocks are in flight in the one launch) or NULL. */
+ * diagonal and off-diagonal tiles separately.  workspace: npw_dgemm_nt_sub_batched_workspace_bytes(count, m, n, k) bytes
+ * (= `count` x the single call's size since version 110: every problem's diagonal blocks are in flight in the one launch)
+ * or NULL.  A caller that sized the buffer by the pre-110 rule (ONE problem's worth) must pass NULL instead. */
+size_t npw_dgemm_nt_sub_batched_workspace_bytes(int count, int64_t m, int64_t n, int64_t k);
 int npw_dgemm_nt_sub_batched(int count, int64_t m, int64_t n, int64_t k, const double* const* S, int64_t lds,
                              const double* const* X, int64_t ldx, const double* const* Y, int64_t ldy,
                              double* const* D, int64_t ldd, const int32_t* const* skip_x,
@@ -316,6 +318,19 @@ int npw_zero_if(double* A, int64_t rows, int64_t cols, int64_t lda, const int32_
  * reference numpywren/kernels.py:154-164,181-208).                            */
 int npw_daxpby(int64_t rows, int64_t cols, double alpha, const double* X, int64_t ldx, double beta,
                const double* Y, int64_t ldy, double* D, int64_t ldd, npw_stream_t stream);
+
+/* D = X * Y elementwise (rows x cols, fp64).  D may alias X or Y exactly.  kernels.mul for two tiles
+ * (reference numpywren/kernels.py:233-234: `x * y`).                          */
+int npw_dmul(int64_t rows, int64_t cols, const double* X, int64_t ldx, const double* Y, int64_t ldy, double* D, int64_t ldd,
+             npw_stream_t stream);
+
+/* B = A with its rows and / or its columns in reverse order (B[r][c] = A[rows - 1 - r][cols - 1 - c] for both).  No
+ * aliasing.  Reversing both orders turns an upper triangle into a lower one: the three forms of kernels.trsm other than
+ * the default (`lower=True`, `right=False`: reference numpywren/kernels.py:254-257 passes them to DTRSM) and
+ * kernels.trsm_sub (kernels.py:178-179, solve_triangular of the upper triangle) run on the one solve the library
+ * has, X L^T = Y, through this and npw_dtranspose.                             */
+int npw_dflip(int64_t rows, int64_t cols, const double* A, int64_t lda, double* B, int64_t ldb, int flip_rows, int flip_cols,
+              npw_stream_t stream);
 
 /* B = A^T (A rows x cols, B cols x rows).  No aliasing.  Replaces the per-tile
  * `.T` of BigMatrixView (reference numpywren/matrix.py:646-647,658-659).      */

@@ -68,6 +68,7 @@ PROTOTYPES = {
                           _i64, _vp, _vp]),
     "npw_dgemm_nt_sub_workspace_bytes": (c_size_t, [_i64, _i64, _i64]),
     "npw_dgemm_nt_sub": (c_int, [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "npw_dgemm_nt_sub_batched_workspace_bytes": (c_size_t, [c_int, _i64, _i64, _i64]),
     "npw_dgemm_nt_sub_batched": (c_int, [c_int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "npw_dtrsm_rltn_workspace_bytes": (_sz, [_i64, _i64]),
     "npw_dtrsm_rltn": (c_int, [_i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
@@ -96,6 +97,8 @@ PROTOTYPES = {
     "npw_is_zero_batched": (c_int, [c_int, _vp, _i64, _i64, _i64, c_double, _vp, _vp]),
     "npw_zero_if": (c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "npw_daxpby": (c_int, [_i64, _i64, c_double, _vp, _i64, c_double, _vp, _i64, _vp, _i64, _vp]),
+    "npw_dmul": (c_int, [_i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "npw_dflip": (c_int, [_i64, _i64, _vp, _i64, _vp, _i64, c_int, c_int, _vp]),
     "npw_dtranspose": (c_int, [_i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     "npw_stranspose": (c_int, [_i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     "npw_dtri_keep": (c_int, [c_char, c_int, _i64, _i64, _vp, _i64, _vp]),

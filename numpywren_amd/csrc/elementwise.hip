@@ -154,6 +154,16 @@ __global__ void axpby_kernel(int64_t rows, int64_t cols, double alpha, const dou
     }
 }
 
+__global__ void mul_kernel(int64_t rows, int64_t cols, const double* X, int64_t ldx, const double* Y, int64_t ldy, double* D,
+                           int64_t ldd) {
+    NPW_FOR_2D(r, c, rows, cols) { D[r * ldd + c] = X[r * ldx + c] * Y[r * ldy + c]; }
+}
+
+// B[r][c] = A[fr ? rows - 1 - r : r][fc ? cols - 1 - c : c]
+__global__ void flip_kernel(int64_t rows, int64_t cols, const double* A, int64_t lda, double* B, int64_t ldb, int fr, int fc) {
+    NPW_FOR_2D(r, c, rows, cols) { B[r * ldb + c] = A[(fr ? rows - 1 - r : r) * lda + (fc ? cols - 1 - c : c)]; }
+}
+
 template <typename T>
 __global__ void transpose_kernel(int64_t rows, int64_t cols, const T* A, int64_t lda, T* B, int64_t ldb) {
     __shared__ T tile[32][33];
@@ -363,6 +373,25 @@ int npw_daxpby(int64_t rows, int64_t cols, double alpha, const double* X, int64_
     NPW_REQUIRE(X && Y && D && ldx >= cols && ldy >= cols && ldd >= cols, "npw_daxpby: bad arguments");
     hipLaunchKernelGGL(axpby_kernel, grid2d(rows, cols), dim3(kThreads), 0, as_stream(stream), rows,
                        cols, alpha, X, ldx, beta, Y, ldy, D, ldd);
+    NPW_LAUNCH_CHECK();
+    return NPW_OK;
+}
+
+int npw_dmul(int64_t rows, int64_t cols, const double* X, int64_t ldx, const double* Y, int64_t ldy, double* D, int64_t ldd,
+             npw_stream_t stream) {
+    if (rows <= 0 || cols <= 0) return NPW_OK;
+    NPW_REQUIRE(X && Y && D && ldx >= cols && ldy >= cols && ldd >= cols, "npw_dmul: bad arguments");
+    hipLaunchKernelGGL(mul_kernel, grid2d(rows, cols), dim3(kThreads), 0, as_stream(stream), rows, cols, X, ldx, Y, ldy, D, ldd);
+    NPW_LAUNCH_CHECK();
+    return NPW_OK;
+}
+
+int npw_dflip(int64_t rows, int64_t cols, const double* A, int64_t lda, double* B, int64_t ldb, int flip_rows, int flip_cols,
+              npw_stream_t stream) {
+    if (rows <= 0 || cols <= 0) return NPW_OK;
+    NPW_REQUIRE(A && B && A != B && lda >= cols && ldb >= cols, "npw_dflip: bad arguments");
+    hipLaunchKernelGGL(flip_kernel, grid2d(rows, cols), dim3(kThreads), 0, as_stream(stream), rows, cols, A, lda, B, ldb, flip_rows,
+                       flip_cols);
     NPW_LAUNCH_CHECK();
     return NPW_OK;
 }

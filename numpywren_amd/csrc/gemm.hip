@@ -1034,6 +1034,10 @@ int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t l
 // npw_dgemm_nt_sub computes it (same tiles, same order of products).  When EVERY problem has X[z] == Y[z] (and the
 // symmetric route's shape) the batch takes that route: one launch over all problems' strictly-lower tile pairs, then
 // the diagonal blocks problem by problem (workspace: npw_dgemm_nt_sub_workspace_bytes(m, n, k), may be NULL).
+size_t npw_dgemm_nt_sub_batched_workspace_bytes(int count, int64_t m, int64_t n, int64_t k) {
+    return count <= 0 ? 0 : (size_t)count * npw_dgemm_nt_sub_workspace_bytes(m, n, k);
+}
+
 int npw_dgemm_nt_sub_batched(int count, int64_t m, int64_t n, int64_t k, const double* const* S, int64_t lds,
                              const double* const* X, int64_t ldx, const double* const* Y, int64_t ldy, double* const* D,
                              int64_t ldd, const int32_t* const* skip_x, const int32_t* const* skip_y, void* workspace,

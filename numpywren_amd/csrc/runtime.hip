@@ -196,7 +196,7 @@ int stream_cu_count_query(hipStream_t s) {
 
 extern "C" {
 
-int npw_version(void) { return 100; }
+int npw_version(void) { return 110; }   // 110: npw_dgemm_nt_sub_batched_workspace_bytes (the batched workspace is per problem), npw_dmul, npw_dflip
 
 namespace {
 struct Roctx {

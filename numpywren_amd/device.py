@@ -1083,7 +1083,7 @@ class HipBackend(object):
                     self._use(sh, problems[i][0], problems[i][1], problems[i][2], out)
                 ws = None
                 if sym:
-                    nbytes = self.lib.npw_dgemm_nt_sub_workspace_bytes(m, n, k) * count   # (per problem: npw_hip.h)
+                    nbytes = self.lib.npw_dgemm_nt_sub_batched_workspace_bytes(count, m, n, k)
                     if nbytes:
                         ws = self.alloc(nbytes)
                         ws.streams.add(sh)
@@ -1462,6 +1462,31 @@ class HipBackend(object):
         out = self.empty(X.shape, _F64)
         self._use(sh, X, Y, out)
         _ffi.check(self.lib.npw_daxpby(r, c, float(alpha), X.ptr, c, float(beta), Y.ptr, c, out.ptr, c, sh), "axpby")
+        self._produced(sh, out)
+        return out
+
+    def mul(self, X, Y, stream=None):
+        """X * Y elementwise for same-shape tiles (kernels.mul on two tiles); fp64 arithmetic."""
+        sh = self._sh(stream)
+        X, Y = self.as_f64(X, sh), self.as_f64(Y, sh)
+        if X.shape != Y.shape:
+            raise ValueError(f"operands could not be broadcast together with shapes {X.shape} {Y.shape}")
+        r, c = X.rows_cols()
+        out = self.empty(X.shape, _F64)
+        self._use(sh, X, Y, out)
+        _ffi.check(self.lib.npw_dmul(r, c, X.ptr, c, Y.ptr, c, out.ptr, c, sh), "mul")
+        self._produced(sh, out)
+        return out
+
+    def flip(self, tile, rows=True, cols=True, stream=None):
+        """The tile with its rows and / or columns in reverse order (np.flip)."""
+        self._require_2d(tile, "flip")
+        sh = self._sh(stream)
+        tile = self.as_f64(tile, sh)
+        r, c = tile.shape
+        out = self.empty((r, c), _F64)
+        self._use(sh, tile, out)
+        _ffi.check(self.lib.npw_dflip(r, c, tile.ptr, c, out.ptr, c, int(bool(rows)), int(bool(cols)), sh), "flip")
         self._produced(sh, out)
         return out
 

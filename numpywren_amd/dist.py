@@ -618,6 +618,7 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
     clock = time.perf_counter
     sent0, recv0 = comm.bytes_sent, comm.bytes_received
     program._defer_success = True
+    program._distributed_world = int(getattr(comm, "world", 1) or 1)    # (checkpoint.save refuses a run over several ranks)
     try:
         # prologue: input tiles read by tasks that live on another rank than the tile itself (one grouped push per tile)
         moves = collections.OrderedDict()
@@ -739,6 +740,7 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
     finally:
         program._defer_success = False
         program.decr_up(1)
+        ex.release_spill_plan()
     diag = {"rank": rank, "transport": comm.backend, "positions": step, "tasks_run_here": len(executed),
             # the common walk on the host, without the time it spent blocked in dist.py's OWN waits (the run-ahead bound, the
             # control group).  It still contains what the walk spent blocked INSIDE HIP calls: a launch returns late when the

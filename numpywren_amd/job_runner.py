@@ -245,7 +245,28 @@ class LambdaPackExecutor(object):
                     # nothing has ever been pushed out: the plan (a dry walk of the scheduling loop, ~0.07 ms per task) is
                     # only made if the allocator's out-of-memory handler asks the tier for memory during this run
                     res.plan = None
+                    res.last_policy = "lru"
                     res.plan_factory = self._install_spill_plan
+            elif not self.dry:
+                # no plan wanted (executor.spill_plan off, the host tier): whatever an earlier run left behind must not steer
+                # this one's evictions
+                res.plan = res.plan_factory = None
+                res.last_policy = "lru"
+
+    def release_spill_plan(self):
+        """The run is over: the process-wide residency tier must not keep this executor's plan, nor the bound method that
+        would build it (it holds the executor and the program alive, and a later out-of-memory reclaim would dry-walk a
+        finished program and install a plan in which every tile's next use is "never")."""
+        try:
+            from . import matrix
+            res = matrix.RESIDENCY
+        except Exception:
+            return
+        if self.spill_plan is not None and getattr(res, "plan", None) is self.spill_plan:
+            res.plan = None
+        fac = getattr(res, "plan_factory", None)
+        if fac is not None and getattr(fac, "__self__", None) is self:
+            res.plan_factory = None
 
     def _has_spilled_tiles(self):
         from .device import SpilledTile
@@ -277,11 +298,19 @@ class LambdaPackExecutor(object):
             return (m.bucket, m.key_base, m.__shard_idx_to_key__(idx))
         try:
             self.spill_plan = SpillPlan(order, key_of)
+            # a resumed program (a second lambdapack_run after a time limit, checkpoint.load + resume): the tasks that are
+            # FINISHED will never be issued by this run -- their reads must not count as upcoming (prefetch would bring
+            # back dead tiles, the farthest-next-read rule would keep them)
+            seen = set(self._issued_idx)
+            for t in tasks:
+                if t.index not in seen and self.program.get_node_status(t.expr_idx, t.vars) == lp.NS.FINISHED:
+                    self.spill_plan.issued(t.index)
             for i in self._issued_idx:
                 self.spill_plan.issued(i)
         except Exception:
             self.spill_plan = None     # (a matrix without the tile-key surface: the tier falls back to LRU)
         matrix.RESIDENCY.plan = self.spill_plan
+        matrix.RESIDENCY.last_policy = "plan" if self.spill_plan is not None else "lru"
         return self.spill_plan
 
     def _issued(self, tasks):
@@ -980,6 +1009,7 @@ def lambdapack_run(program, pipeline_width=1, msg_vis_timeout=60, cache_size=5, 
         raise
     finally:
         program.decr_up(1)
+        ex.release_spill_plan()
     t_stop = time.time()
     return {"up_time": [t_start, t_stop],
             "exec_time": calculate_busy_time(running_times),

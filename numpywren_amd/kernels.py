@@ -155,21 +155,44 @@ def _syrk_batch(be, stream, arg_lists, kwargs_list):
 syrk._npw_batch = _syrk_batch
 
 
+def _solve_right_upper(be, stream, L, Y, exact):
+    """X with X L^T = Y, L lower triangular: the one triangular solve the library has (npw_dtrsm_rltn_inv)."""
+    return be.trsm(L, Y, stream, exact_zero=exact)
+
+
+def _solve_right_lower(be, stream, M, Y, exact):
+    """X with X M = Y, M lower triangular.  With J the reversal permutation, (X J)(J M J) = Y J and J M J is upper
+    triangular: the library's solve with L' = (J M J)^T = J M^T J and the columns of Y reversed; X is the result with
+    its columns reversed again (npw_dflip)."""
+    Lp = be.flip(be.transpose(M, stream), True, True, stream)
+    return be.flip(be.trsm(Lp, be.flip(Y, False, True, stream), stream, exact_zero=exact), False, True, stream)
+
+
 @_kernel
 def _trsm(be, stream, x, y, lower=False, right=True, *args, **kwargs):
-    """Solve X . x^T = y, x lower triangular (reference kernels.py:254-257:
-    scipy.linalg.blas.dtrsm(1.0, x.T, y, lower=False, side=1)); zeros((x.shape[1], y.shape[0])) when
-    y is allclose to 0."""
-    if lower or not right:
-        raise NotImplementedError("trsm: only the reference's defaults lower=False, right=True are implemented "
-                                  "(the only form the LambdaPACK programs use)")
+    """scipy.linalg.blas.dtrsm(1.0, x.T, y, lower=lower, side=int(right)) (reference kernels.py:254-257); zeros((x.shape[1],
+    y.shape[0])) when y is allclose to 0.  With a = x.T, DTRSM reads only a's upper (lower=False) or lower triangle:
+      lower=False, right=True  (the default, all the LambdaPACK programs use):  X triu(a) = y  <=>  X tril(x)^T = y
+      lower=True,  right=True :  X tril(a) = y          -- a lower triangular matrix on the right (see _solve_right_lower)
+      lower=True,  right=False:  tril(a) X = y  <=>  X^T tril(a)^T = y^T       -- the library's solve on transposes
+      lower=False, right=False:  triu(a) X = y  <=>  X^T tril(x) = y^T         -- lower triangular on the right, transposed
+    """
     exact = _ctx()[2]
-    out = be.trsm(x, y, stream, exact_zero=exact)
-    if exact and y.shape[0] != x.shape[1]:
-        # non-square: the reference's zero short-circuit changes the result SHAPE, which needs the
-        # flag on the host
+    lower, right = bool(lower), bool(right)
+    if not lower and right:
+        out = _solve_right_upper(be, stream, x, y, exact)
+    elif lower and right:
+        out = _solve_right_lower(be, stream, be.tri(be.transpose(x, stream), "L", False, stream), y, exact)
+    elif lower and not right:
+        out = be.transpose(_solve_right_upper(be, stream, be.tri(be.transpose(x, stream), "L", False, stream),
+                                              be.transpose(y, stream), exact), stream)
+    else:
+        out = be.transpose(_solve_right_lower(be, stream, be.tri(x, "L", False, stream), be.transpose(y, stream), exact), stream)
+    zshape = (x.shape[1], y.shape[0])
+    if exact and tuple(out.shape) != zshape:
+        # the reference's zero short-circuit changes the result SHAPE, which needs the flag on the host
         if be.read_flag(be.zero_flag(y, stream), stream):
-            return be.zeros((x.shape[1], y.shape[0]), np.float64, stream)
+            return be.zeros(zshape, np.float64, stream)
     return out
 
 
@@ -269,10 +292,9 @@ identity._npw_device_kernel = True
 
 @_kernel
 def _mul(be, stream, x, y, *args, **kwargs):
-    """x * y for a scalar and a tile (reference kernels.py:233-234); tile * tile is not on any
-    LambdaPACK program's path."""
+    """x * y (reference kernels.py:233-234): a scalar and a tile, or two tiles of one shape elementwise (npw_dmul)."""
     if isinstance(x, DeviceTile) and isinstance(y, DeviceTile):
-        raise NotImplementedError("mul(tile, tile) is not implemented on the HIP path")
+        return be.mul(x, y, stream)
     if isinstance(y, DeviceTile):
         x, y = y, x
     return be.axpby(float(y), x, 0.0, x, stream)
@@ -494,6 +516,23 @@ gemm._npw_chain_weight = lambda task: 1.0
 slow_qr = _qr_factor   # reference kernels.py:67-84 (DGEQRF + DLARFT): same (V, T, R); npw_dgeqrt takes any m, n
 
 
+def _tpqrt_shapes(x0, x1):
+    """The shapes the reference's DTPQRT call (kernels.py:107-124) accepts: it passes m = l = x0.shape[0], n = x0.shape[1],
+    a = x0, b = x1.  LAPACK wants A n x n (LDA >= n), B with at least m rows and l <= min(m, n), so x0 has to be square
+    (m > n: l > min(m, n), argument 3; m < n: LDA < n, argument 6) and x1 needs n columns and at least n rows, of which the
+    routine only touches the first n.  Anything else is LAPACK's "illegal value" error there, a ValueError here."""
+    if x0.ndim != 2 or x1.ndim != 2:
+        raise ValueError(f"qr_factor_triangular: 2-D tiles expected, got {tuple(x0.shape)} over {tuple(x1.shape)}")
+    m, n = x0.shape
+    if m > n:
+        raise ValueError(f"qr_factor_triangular: x0 is {m} x {n}; DTPQRT(m={m}, n={n}, l={m}) has l > min(m, n) (illegal argument 3)")
+    if m < n:
+        raise ValueError(f"qr_factor_triangular: x0 is {m} x {n}; DTPQRT's A must be n x n (illegal argument 6, lda < n)")
+    if x1.shape[1] != n or x1.shape[0] < n:
+        raise ValueError(f"qr_factor_triangular: x1 is {tuple(x1.shape)}; DTPQRT(m={n}, n={n}) needs at least {n} rows of {n} columns")
+    return n
+
+
 @_kernel
 def _qr_factor_triangular(be, stream, x0, x1, **kwargs):
     """QR of two stacked upper-triangular tiles (reference kernels.py:107-124: LAPACK DTPQRT with l = m,
@@ -507,11 +546,9 @@ def _qr_factor_triangular(be, stream, x0, x1, **kwargs):
          it as written -- see tests/golden/make_golden_qr.py and DESIGN.md section 7.)
     On the GPU: npw_dtpqrt_batched (the structured factorisation of two stacked triangles) gives R and the full n x n T,
     whose nb x nb diagonal blocks are DTPQRT's blocked T (npw_dblockdiag_rows lays them side by side)."""
-    n = x0.shape[-1]
-    if tuple(x0.shape) != (n, n) or tuple(x1.shape) != (n, n):
-        raise NotImplementedError(f"qr_factor_triangular of {x0.shape} over {x1.shape}: only square tiles of equal size "
-                                  "(all the QR tree produces) are supported")
-    _, T, R = be.tpqrt_batched([(be.tri(x0, "U", False, stream), be.tri(x1, "U", False, stream))], stream)[0]
+    n = _tpqrt_shapes(x0, x1)
+    x1top = x1 if x1.shape[0] == n else be.rows(x1, 0, n, stream)
+    _, T, R = be.tpqrt_batched([(be.tri(x0, "U", False, stream), be.tri(x1top, "U", False, stream))], stream)[0]
     v = be.tri(x1, "L", True, stream)
     t = be.blockdiag_rows(T, min(n, 32), stream)
     return v, t, R
@@ -526,11 +563,8 @@ def _qr_factor_triangular_batch(be, stream, arg_lists, kwargs_list):
     """Independent qr_factor_triangular tasks (the nodes of one level of the QR tree, reference algs.py:182-234) as one
     batched factorisation; same outputs as _qr_factor_triangular for each."""
     for x0, x1 in arg_lists:
-        n = x0.shape[-1]
-        if tuple(x0.shape) != (n, n) or tuple(x1.shape) != (n, n):
-            raise NotImplementedError(f"qr_factor_triangular of {x0.shape} over {x1.shape}: only square tiles of equal size "
-                                      "(all the QR tree produces) are supported")
-    if len({tuple(x0.shape) for x0, _ in arg_lists}) != 1:
+        _tpqrt_shapes(x0, x1)
+    if len({(tuple(x0.shape), tuple(x1.shape)) for x0, x1 in arg_lists}) != 1 or arg_lists[0][1].shape[0] != arg_lists[0][0].shape[0]:
         return [_qr_factor_triangular(x0, x1) for x0, x1 in arg_lists]
     stacked = [(be.tri(x0, "U", False, stream), be.tri(x1, "U", False, stream)) for x0, x1 in arg_lists]
     out = []
@@ -588,5 +622,16 @@ def banded_to_bidiagonal(x):
     return d_all.reshaped((d_all.shape[0],)), e_all.reshaped((e_all.shape[0],))
 
 
-def trsm_sub(L, S, x):
-    raise NotImplementedError("trsm_sub (reference kernels.py:178-179) is unused by the LambdaPACK programs")
+@_kernel
+def _trsm_sub(be, stream, L, S, x, *args, **kwargs):
+    """scipy.linalg.solve_triangular(L, x - S) (reference kernels.py:178-179): solve_triangular's default is lower=False, so
+    this is X with triu(L) X = x - S.  Transposed, X^T triu(L)^T = (x - S)^T: a lower triangular matrix on the right
+    (_solve_right_lower).  Unused by the LambdaPACK programs; kept because it is part of the reference's kernel surface."""
+    rhs = be.axpby(1.0, x, -1.0, S, stream)
+    if rhs.ndim != 2 or L.ndim != 2 or L.shape[0] != L.shape[1] or rhs.shape[0] != L.shape[0]:
+        raise ValueError(f"trsm_sub: incompatible shapes L{tuple(L.shape)} x{tuple(rhs.shape)}")
+    M = be.transpose(be.tri(L, "U", False, stream), stream)
+    return be.transpose(_solve_right_lower(be, stream, M, be.transpose(rhs, stream), False), stream)
+
+
+trsm_sub = _trsm_sub

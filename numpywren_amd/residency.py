@@ -119,6 +119,8 @@ class Residency(object):
         self._hooked = None
         self.plan = None          # SpillPlan of the program being run (LambdaPackExecutor installs it)
         self.plan_factory = None  # ... or how to make it, when the tier was idle as the run began (called at the first need)
+        self.last_policy = "lru"  # what chose the victims of the most recent run ("plan" once a plan was installed; the plan
+                                  # itself is dropped when its run ends -- job_runner.release_spill_plan)
 
     # ---- configuration ----
     @property
@@ -147,11 +149,12 @@ class Residency(object):
             self._budget_known = False
             self.evictions = self.restores = self.prefetched = self.written_through = 0
             self.plan = self.plan_factory = None
+            self.last_policy = "lru"
 
     def stats(self):
         return {"resident_bytes": self.resident_bytes, "resident_tiles": len(self.lru), "budget": self._budget,
                 "evictions": self.evictions, "restores": self.restores, "prefetched": self.prefetched, "written_through": self.written_through,
-                "policy": "plan" if self.plan is not None else "lru"}
+                "policy": "plan" if self.plan is not None else self.last_policy}
 
     def _hook(self, be):
         # the allocator asks us for memory before it reports out-of-memory

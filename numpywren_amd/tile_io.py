@@ -67,21 +67,35 @@ def tile_bytes(array):
     return bio.getvalue()
 
 
-def export_matrix(bigm, root):
-    """Write the header object and every stored tile of `bigm` under `root`; returns the number of tile objects."""
+def export_matrix(bigm, root, atomic=False, return_keys=False):
+    """Write the header object and every stored tile of `bigm` under `root`; returns the number of tile objects (or, with
+    return_keys, their object names relative to the matrix).  atomic: every object goes to a temporary name first and is
+    renamed into place (checkpoint.save)."""
+    def put(path, data, mode):
+        if not atomic:
+            with open(path, mode) as f:
+                f.write(data)
+            return
+        tmp = path + ".tmp"
+        with open(tmp, mode) as f:
+            f.write(data)
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(tmp, path)
+
     hdr = {"shape": [int(s) for s in bigm.shape], "shard_sizes": [int(s) for s in bigm.shard_sizes],
            "dtype": encode_dtype(bigm.dtype)}
     hpath = _object_path(root, bigm.bucket, os.path.join(bigm.key_base, "header"))
     os.makedirs(os.path.dirname(hpath), exist_ok=True)
-    with open(hpath, "w") as f:
-        json.dump(hdr, f)
+    put(hpath, json.dumps(hdr), "w")
     with OBJECTS.lock:
         tiles = dict(OBJECTS.tiles(bigm.bucket, bigm.key_base, create=False) or {})
     for key, tile in tiles.items():
         path = _object_path(root, bigm.bucket, key)
         os.makedirs(os.path.dirname(path), exist_ok=True)
-        with open(path, "wb") as f:
-            f.write(tile_bytes(_host_array(tile)))
+        put(path, tile_bytes(_host_array(tile)), "wb")
+    if return_keys:
+        return sorted(os.path.basename(k) for k in tiles)
     return len(tiles)
 
 
@@ -91,12 +105,14 @@ def read_header(root, key, bucket=DEFAULT_BUCKET, prefix=DEFAULT_PREFIX):
     return {"shape": tuple(hdr["shape"]), "shard_sizes": tuple(hdr["shard_sizes"]), "dtype": decode_dtype(hdr["dtype"])}
 
 
-def _load_tiles(bigm, root):
+def _load_tiles(bigm, root, only=None):
     base = _object_path(root, bigm.bucket, bigm.key_base)
     n = 0
     if not os.path.isdir(base):
         return 0
     for name in sorted(os.listdir(base)):
+        if name.endswith(".tmp") or (only is not None and name not in only):
+            continue            # (an interrupted atomic write; an object that is not part of the checkpoint being loaded)
         ranges = block_key_to_block(name)
         if ranges is None:      # the header object
             continue
@@ -125,6 +141,6 @@ def spill(bigm, root):
     return n
 
 
-def restore(bigm, root):
-    """Inverse of spill: bring the tile objects under `root` back into the store."""
-    return _load_tiles(bigm, root)
+def restore(bigm, root, only=None):
+    """Inverse of spill: bring the tile objects under `root` back into the store (`only`: just these object names)."""
+    return _load_tiles(bigm, root, only)

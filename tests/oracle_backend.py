@@ -246,3 +246,14 @@ class OracleBackend(object):
 
     def axpby(self, alpha, X, beta, Y, stream=None):
         return HostTile(alpha * X.array + beta * Y.array)
+
+    def mul(self, X, Y, stream=None):
+        return HostTile(np.asarray(X.array, dtype=np.float64) * np.asarray(Y.array, dtype=np.float64))
+
+    def flip(self, tile, rows=True, cols=True, stream=None):
+        a = tile.array
+        if rows:
+            a = a[::-1]
+        if cols:
+            a = a[:, ::-1]
+        return HostTile(np.ascontiguousarray(a, dtype=np.float64))

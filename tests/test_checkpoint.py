@@ -125,3 +125,81 @@ def test_checkpoint_on_the_gpu(hbm_store, tmp_path):
     L = meta2["outputs"][0].numpy()
     np.testing.assert_allclose(L, L_ref, rtol=1e-13, atol=1e-12)
     np.testing.assert_allclose(np.tril(L), np.linalg.cholesky(a), rtol=1e-10, atol=1e-9)
+
+
+def _gemm_program(tag, A, B, b, fuse=True):
+    from numpywren_amd.matrix_init import shard_matrix
+    Ab = BigMatrix(f"ckg_A_{tag}", shape=A.shape, shard_sizes=(b, b), write_header=True)
+    Bb = BigMatrix(f"ckg_B_{tag}", shape=B.shape, shard_sizes=(b, b), write_header=True)
+    shard_matrix(Ab, A)
+    shard_matrix(Bb, B)
+    program, meta = alg_wrappers.gemm(Ab, Bb)
+    program.config["executor"]["fuse_gemm_reduction"] = fuse
+    return program, meta
+
+
+@pytest.mark.parametrize("done_first", [3, 10, 40, 64])
+def test_fused_gemm_resumes_from_a_checkpoint(oracle_backend, tmp_path, done_first):
+    """executor.fuse_gemm_reduction keeps the partial sums of unfinished C tiles outside the tile store: the
+    products that went into a still-open accumulator are saved as NOT finished and run again after the resume."""
+    rng = np.random.default_rng(21)
+    n, b = 32, 8
+    A, B = rng.standard_normal((n, n)), rng.standard_normal((n, n))
+    program, meta = _gemm_program("x", A, B, b)
+    program.start()
+    _run_some(program, done_first)
+    saved = checkpoint.save(program, str(tmp_path))
+    assert saved["finished"] <= done_first                         # open accumulators' products do not count
+    if done_first == 3:
+        assert saved["finished"] == 0                               # no C tile has all four products yet
+    matrix.OBJECTS.clear()
+    program2, meta2 = _gemm_program("x", A, B, b)
+    left = checkpoint.load(program2, str(tmp_path))
+    assert left == saved["tasks"] - saved["finished"]
+    job_runner.lambdapack_run(program2)
+    program2.wait()
+    assert program2.program_status() == lp.PS.SUCCESS, program2.exceptions
+    np.testing.assert_allclose(meta2["outputs"][0].numpy(), A @ B, rtol=1e-12, atol=1e-12)
+
+
+def test_checkpoint_is_atomic_and_lists_its_tiles(oracle_backend, tmp_path):
+    """A second save into the same root after intermediates were reclaimed must not bring their old tile objects back; an
+    interrupted write (a leftover .tmp) is ignored; a program in EXCEPTION state and a distributed run are refused."""
+    import glob
+    import os
+    rng = np.random.default_rng(14)
+    n, b = 32, 8
+    x = rng.standard_normal((n, n))
+    a = x @ x.T + n * np.eye(n)
+    X = _input(a, b, key="ckpt_at")
+    program, meta = alg_wrappers.cholesky(X)
+    program.config["executor"]["reclaim_intermediates"] = True
+    program.start()
+    _run_some(program, 6)
+    first = checkpoint.save(program, str(tmp_path))
+    _run_some(program, 10)
+    second = checkpoint.save(program, str(tmp_path))
+    assert second["finished"] == 16
+    inter = meta["intermediates"][0]
+    on_disk = len(glob.glob(os.path.join(str(tmp_path), inter.bucket, inter.key_base, "*_*")))
+    assert on_disk > len(inter.block_idxs_exist)                   # stale objects of reclaimed tiles are still on disk ...
+    assert not glob.glob(os.path.join(str(tmp_path), "**", "*.tmp"), recursive=True)
+    open(os.path.join(str(tmp_path), inter.bucket, inter.key_base, "0_8_8_0_8_8_0_8_8_.tmp"), "wb").write(b"torn")
+    matrix.OBJECTS.clear()
+    X2 = BigMatrix("ckpt_at", shape=a.shape, shard_sizes=(b, b), write_header=True)
+    program2, meta2 = alg_wrappers.cholesky(X2)
+    program2.config["executor"]["reclaim_intermediates"] = True
+    checkpoint.load(program2, str(tmp_path))
+    assert len(meta2["intermediates"][0].block_idxs_exist) == len(inter.block_idxs_exist) < on_disk   # ... and stay there
+    job_runner.lambdapack_run(program2)
+    program2.wait()
+    assert program2.program_status() == lp.PS.SUCCESS, program2.exceptions
+    np.testing.assert_allclose(np.tril(meta2["outputs"][0].numpy()), np.linalg.cholesky(a), rtol=1e-12, atol=1e-12)
+    assert first["tiles"] > 0
+    program2._distributed_world = 2
+    with pytest.raises(NotImplementedError):
+        checkpoint.save(program2, str(tmp_path), name="d")
+    program2._distributed_world = 1
+    program2.handle_exception("boom", tb="", expr_idx=0, var_values={})
+    with pytest.raises(ValueError):
+        checkpoint.save(program2, str(tmp_path), name="e")

@@ -330,3 +330,49 @@ def test_allocation_failure_pushes_tiles_out(hbm_store, monkeypatch):
     assert matrix.RESIDENCY.stats()["restores"] == 4
     m.free()
     be.trim_pinned()
+
+
+def test_plan_of_a_resumed_run_skips_finished_tasks_and_is_released_at_the_end(oracle_backend):
+    """a second lambdapack_run on a program that stopped on its time limit builds its plan from all tasks; the
+    FINISHED ones are never issued again, so they must count as issued (their reads are not "upcoming").  When a run ends
+    the process-wide tier must not keep the executor's plan or the factory bound to it."""
+    from numpywren_amd import alg_wrappers, job_runner
+    from numpywren_amd import lambdapack as lp
+    rng = np.random.default_rng(5)
+    n, b = 64, 16
+    x = rng.standard_normal((n, n))
+    a = x @ x.T + n * np.eye(n)
+    A = BigMatrix("res_resume_in", shape=(n, n), shard_sizes=(b, b), write_header=True)
+    matrix.RESIDENCY.set_budget(6 * TILE)
+    for i in range(4):
+        for j in range(4):
+            A.put_block(a[i * b:(i + 1) * b, j * b:(j + 1) * b], i, j)
+    program, meta = alg_wrappers.cholesky(A)
+    program.start()
+    ex = job_runner.LambdaPackExecutor(program, pipeline_width=1)
+    for _ in range(7):
+        e, v = program.dequeue()
+        program.set_node_status(e, v, lp.NS.RUNNING)
+        ex.run_task(e, v)
+        program.post_op(e, v, lp.PS.SUCCESS, None)
+        program.set_node_status(e, v, lp.NS.FINISHED)
+    ex.release_spill_plan()
+    ex2 = job_runner.LambdaPackExecutor(program, pipeline_width=1)      # what the second lambdapack_run creates
+    plan = ex2.spill_plan
+    assert plan is not None and matrix.RESIDENCY.plan is plan
+    finished = [t for t in program.program.tasks if program.get_node_status(t.expr_idx, t.vars) == lp.NS.FINISHED]
+    assert len(finished) == 7 and all(plan.done[plan.pos[t.index]] for t in finished)
+    assert sum(plan.done) == 7
+    job_runner.lambdapack_run(program, _executor=ex2)
+    program.wait()
+    assert program.program_status() == lp.PS.SUCCESS
+    assert np.allclose(meta["outputs"][0].numpy(), np.linalg.cholesky(a))
+    assert matrix.RESIDENCY.plan is None and matrix.RESIDENCY.plan_factory is None
+    program.free()
+    # without a budget the plan is only a factory during the run, and gone afterwards
+    matrix.RESIDENCY.set_budget(None)
+    program, meta = alg_wrappers.cholesky(A)
+    program.start()
+    job_runner.lambdapack_run(program)
+    assert matrix.RESIDENCY.plan is None and matrix.RESIDENCY.plan_factory is None
+    program.free()
