@@ -37,6 +37,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (vendor spec)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense fp64 matrix peak (vendor spec; 74.6 measured by tools/devcheck)
 TILE = 4096
 # 65536^2 on ONE GPU: the anchor of the N > 1 strong-scaling lines, and the curve DESIGN.md section 6 predicts from the
@@ -186,22 +187,13 @@ def cpu_baseline(b, budget_s=12.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import npw_oracle as oracle
     rng = np.random.default_rng(0)
-    ncpu = os.cpu_count() or 1
-    probe = 2048
-    a = rng.standard_normal((probe, probe))
-    sweep = {}
-    for th in sorted({1, 32, 64, 128, ncpu} & set(range(1, ncpu + 1)) | {1, ncpu}):
-        with _blas_threads(th):
-            oracle.syrk(a, a, a)                       # warm the pool at this size
-            t0 = time.time()
-            oracle.syrk(a, a, a)
-            sweep[th] = round(2 * probe ** 3 / max(time.time() - t0, 1e-6) / 1e9, 1)
-    best = max(sweep, key=sweep.get)
+    best, sweep = _best_blas_threads(oracle, rng)
 
     def executed(nb):   # flops the tile DAG executes (chol b^3/3, trsm b^3, syrk 2 b^3)
         return (nb * b ** 3 / 3 + nb * (nb - 1) / 2 * b ** 3 + sum((nb - i - 1) * (nb - i) / 2 for i in range(nb)) * 2 * b ** 3)
 
-    out = {"unit": "TFLOP/s", "kind": "port", "blas": _blas_name(), "probe_syrk_2048_gflops_by_threads": sweep}
+    out = {"unit": "TFLOP/s", "kind": "port", "blas": _blas_name() + " (OpenBLAS builds of NumPy / SciPy; MKL is not in this image)",
+           "probe_syrk_2048_gflops_by_threads": sweep}
     for label, th in (("best", best), ("one_thread", 1)):
         # the best setting always runs configs[1]'s own 16384^2 matrix (10 - 25 s on these hosts), so that `value` means
         # the same on every box of the pool; the 1-thread sample is sized to the budget
@@ -239,6 +231,80 @@ def _blas_name():
         return cfg.get("Build Dependencies", {}).get("blas", {}).get("name", "unknown")
     except Exception:
         return "unknown"
+
+
+def _best_blas_threads(oracle, rng):
+    """(threads, {threads: GFLOP/s}) of the 2048^3 syrk probe -- the sweep cpu_baseline() runs for the Cholesky line."""
+    ncpu = os.cpu_count() or 1
+    probe = 2048
+    a = rng.standard_normal((probe, probe))
+    sweep = {}
+    for th in sorted({1, 32, 64, 128, ncpu} & set(range(1, ncpu + 1)) | {1, ncpu}):
+        with _blas_threads(th):
+            oracle.syrk(a, a, a)
+            t0 = time.time()
+            oracle.syrk(a, a, a)
+            sweep[th] = round(2 * probe ** 3 / max(time.time() - t0, 1e-6) / 1e9, 1)
+    return max(sweep, key=sweep.get), sweep
+
+
+def cpu_baseline_tsqr(b, leaves_total, sample_leaves=8):
+    """the oracle's TSQR (oracle.tsqr: LAPACK DGEQRT through SciPy on every leaf and tree node, the
+    reference's fast_qr restated) on a `sample_leaves`-leaf, b-wide slice of the same input, all host cores, scaled to the
+    full problem by algorithmic flops (2 m n^2 - 2 n^3 / 3).  kind = "port": the reference's own LAPACK module is an f2py
+    build it downloads at run time (kernels.py:12-40) and is not in its tree."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import npw_oracle as oracle
+    rng = np.random.default_rng(7)
+    best, sweep = _best_blas_threads(oracle, rng)
+    m = sample_leaves * b
+    X = rng.standard_normal((m, b))
+    with _blas_threads(best):
+        t0 = time.time()
+        oracle.tsqr(X, b)
+        dt = time.time() - t0
+    flops = 2.0 * m * b * b - 2.0 * b ** 3 / 3
+    full = 2.0 * leaves_total * b * b * b - 2.0 * b ** 3 / 3
+    tf = flops / dt / 1e12
+    return {"value": round(tf, 4), "unit": "TFLOP/s", "cores": best, "kind": "port",
+            "blas": _blas_name() + " (OpenBLAS build of SciPy; MKL is not in this image)", "probe_syrk_2048_gflops_by_threads": sweep,
+            "seconds": round(dt, 2), "extrapolated_full_problem_s": round(full / (tf * 1e12), 1),
+            "sample": f"oracle TSQR (SciPy LAPACK DGEQRT on {sample_leaves} leaves + {sample_leaves - 1} tree nodes) of a {m}x{b} fp64 "
+                      f"slice at {best} BLAS threads, {round(dt, 1)} s; the {leaves_total}-leaf problem is extrapolated by "
+                      f"algorithmic flops, not run"}
+
+
+def cpu_baseline_gemm32(b, nb):
+    """one oracle 4096^3 sgemm (kernels.gemm restated: A.dot(B) on float32 tiles), all host cores, median
+    of 3; the nb^3 products of the program (and nothing for its fp64 add tree) extrapolated."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import npw_oracle as oracle
+    rng = np.random.default_rng(11)
+    best, sweep = _best_blas_threads(oracle, rng)
+    A = rng.standard_normal((b, b)).astype(np.float32)
+    B_ = rng.standard_normal((b, b)).astype(np.float32)
+    with _blas_threads(best):
+        oracle.gemm(A, B_)
+        ts = []
+        for _ in range(3):
+            t0 = time.time()
+            oracle.gemm(A, B_)
+            ts.append(time.time() - t0)
+    med = float(np.median(ts))
+    tf = 2.0 * b ** 3 / med / 1e12
+    return {"value": round(tf, 4), "unit": "TFLOP/s", "cores": best, "kind": "port",
+            "blas": _blas_name() + " (OpenBLAS build of NumPy; MKL is not in this image)", "probe_syrk_2048_gflops_by_threads": sweep,
+            "median_s": round(med, 4), "extrapolated_full_problem_s": round(nb ** 3 * med, 1),
+            "sample": f"one oracle {b}^3 fp32 gemm (NumPy sgemm) at {best} BLAS threads, median of 3; the program's {nb ** 3} "
+                      f"products are extrapolated (its fp64 add_matrices tree not counted), not run"}
+
+
+def _profile_json(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except Exception:
+        return None
 
 
 def _prebuild(build, count):
@@ -409,6 +475,43 @@ def one_gpu_anchor(be, comm, rank, what, make_input, build, flops, r_only=False)
             be.trim()
     comm.barrier()
     return anchor
+
+
+def tsqr_roofline(times, b, r_only):
+    """The TSQR line's roofline: the hot path is the C-ABI call npw_dgeqrt_batched (the leaves, batches of 32) and
+    npw_dtpqrt_batched (the tree nodes) -- each a sequence of launches on four streams inside the library, bracketed here by
+    HIP events on the caller's stream (the call joins its helper streams before it returns).  Per tile: algorithmic
+    Householder flops (4/3 b^3 for a leaf, the same count for a 2b x b node as LAPACK's dense DGEQRT would spend: 10/3 b^3 --
+    the structured kernel executes about a third of that, so a node's `frac` can look generous; the leaf is what is quoted)
+    over the measured time per tile.  Both bounds are stated: the MFMA time of those flops at the fp64 peak and the HBM time
+    of the PMC-measured bytes of one batch of 32 at 6.3 TB/s (the achievable rate of MI355X_MICROARCH.md); the larger is `bound`."""
+    leaf = times.get("geqrt_batched", [])
+    node = times.get("tpqrt_batched", [])
+    if not leaf:
+        return None
+    avg_ms = float(np.mean(leaf))
+    flop = 4.0 * b ** 3 / 3
+    achieved = flop / (avg_ms * 1e-3) / 1e12
+    pmc = _profile_json("r06_qr32_hbm_bytes.json") or {}
+    key = "r_only" if r_only else "with_t"
+    bytes32 = (pmc.get(key) or {}).get("bytes_per_batch_of_32")
+    t_mfma = 32 * flop / (FP64_MFMA_PEAK_TFLOPS * 1e12) * 1e3
+    t_hbm = bytes32 / 6.3e12 * 1e3 if bytes32 else None
+    out = {"bound": "hbm" if (t_hbm is not None and t_hbm > t_mfma) else "mfma",
+           "kernel": "npw_dgeqrt_batched x32 (kernels.qr_factor on 32 leaves of 4096^2: panel chain + three levels of block reflectors; "
+                     "dominant device kernels by rocprof share: gemm_kernel<double,128,128,16,true,true,false,3> -- the rank-256 far update -- "
+                     "and gemm_kernel<double,128,256,16,false,false,false,0,4> -- its X^T = W2^T V product; profiles/r06_qr_batched32*_kernel_stats.csv)",
+           "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
+           "launches": len(leaf), "avg_ms": round(avg_ms, 4), "avg_ms_is": "per leaf tile (a call of 32 tiles / 32)",
+           "algorithmic_flop_per_launch": flop,
+           "mfma_bound_ms_per_batch_of_32": round(t_mfma, 2), "hbm_bound_ms_per_batch_of_32": round(t_hbm, 2) if t_hbm else None,
+           "traffic": bytes32, "traffic_unit": "B per batch of 32 leaves (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, separate passes; "
+                                               "profiles/r06_qr32_hbm_bytes.json), not this run; compulsory: read A, write R (+ V, T) = "
+                                               + ("8.6e9" if r_only else "1.72e10")}
+    if node:
+        out["tree_nodes"] = {"launches": len(node), "avg_ms": round(float(np.mean(node)), 4),
+                             "what": "npw_dtpqrt_batched, per node (two stacked 4096^2 triangles)"}
+    return out
 
 
 def main():
@@ -597,7 +700,8 @@ def main():
             if comm is None or comm.owner("A", (j, 0)) == rank:
                 X.put_tile(be.fill_random((b, b), 7, j * b, 0), j, 0)
         be.synchronize()
-        elapsed, meta = run.timed(lambda: alg_wrappers.tsqr(X), args.steps, args.warmup)
+        elapsed, meta = run.timed(lambda: alg_wrappers.tsqr(X), args.steps, args.warmup, timers=("geqrt_batched", "tpqrt_batched"))
+        qr_times = be.collect_kernel_times() if comm is None else {}
         run_step_ms = run.step_ms
         flops = 2.0 * m * b * b - 2.0 * b ** 3 / 3
         value = args.steps * flops / elapsed / 1e12
@@ -608,14 +712,20 @@ def main():
                 "config": {"workload": f"{m}x{b} fp64 TSQR, {leaves} leaves, alg_wrappers.tsqr ({2 * leaves - 1} tasks), "
                                        + ("R only (V / T dropped on store)" if r_only else "R, V, T kept (the reference's outputs)"),
                            "r_only": r_only, "tile": b, "streams": args.streams, "parallelism": par}}
+        if comm is None:
+            line["roofline"] = tsqr_roofline(qr_times, b, r_only)
         if comm is None and not r_only:
             run.r_only = True
-            e2, _ = run.timed(lambda: alg_wrappers.tsqr(X), args.steps, 1)
+            e2, _ = run.timed(lambda: alg_wrappers.tsqr(X), args.steps, 1, timers=("geqrt_batched", "tpqrt_batched"))
+            t2 = be.collect_kernel_times()
             run.r_only = False
             line["config"]["r_only_run"] = {"what": "the same program with executor.drop_unread_outputs: only the R factors are produced",
                                             "ms_per_step": round(e2 / args.steps * 1e3, 3),
                                             "tflops": round(args.steps * flops / e2 / 1e12, 3)}
             line["config"]["r_only_run"].update(step_stats(run.step_ms, line["config"]["r_only_run"]["ms_per_step"], "r_only_run.ms_per_step"))
+            line["config"]["r_only_run"]["roofline"] = tsqr_roofline(t2, b, True)
+        if comm is None and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_tsqr(b, leaves)
     else:
         # configs[4]: 32768^2 fp32 GEMM program (fp32 MFMA products, the reference's fp64 add_matrices tree), strong scaling
         nb = args.tiles or 8
@@ -645,7 +755,8 @@ def main():
                 if comm is None or comm.owner("B", (i, j)) == rank:
                     B.put_tile(be.convert(be.fill_random((b, b), 12, i * b, j * b), np.float32), i, j)
         be.synchronize()
-        elapsed, meta = run.timed(lambda: alg_wrappers.gemm(A, B), args.steps, args.warmup)
+        elapsed, meta = run.timed(lambda: alg_wrappers.gemm(A, B), args.steps, args.warmup, timers=("gemm",))
+        gemm_times = be.collect_kernel_times().get("gemm", []) if comm is None else []
         run_step_ms = run.step_ms
         value = args.steps * 2.0 * n ** 3 / elapsed / 1e12
         line = {"metric": "achieved fp32 TFLOP/s, N x N GEMM program (2 N^3 / wall)", "value": round(value, 3),
@@ -655,6 +766,20 @@ def main():
                 "config": {"workload": f"{n}x{n} fp32 GEMM, {b}^2 tiles, alg_wrappers.gemm (fp32 MFMA products, fp64 "
                                        f"add_matrices tree as in the reference)", "tile": b, "streams": args.streams,
                            "parallelism": par, "pct_fp32_mfma_peak": round(100 * value / (157.3 * args.gpus), 2)}}
+        if comm is None and gemm_times:
+            avg_ms = float(np.mean(gemm_times))
+            achieved = 2.0 * b ** 3 / (avg_ms * 1e-3) / 1e12
+            pmc = _profile_json("r06_gemm32_pmc.json") or {}
+            line["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<float,128,128,32,true,true,false,0,2> (kernels.gemm on two fp32 tiles: "
+                                                           "one 4096^3 product, 1024 workgroups; B tiles transposed once, then the N / T form)",
+                                "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "launches": len(gemm_times), "avg_ms": round(avg_ms, 4),
+                                "algorithmic_flop_per_launch": 2 * b ** 3,
+                                "traffic": pmc.get("bytes_per_launch"),
+                                "traffic_unit": "B per 4096^3 product; from profiles/r06_gemm32_pmc.json (rocprofv3 --pmc, separate passes of "
+                                                "this command), not this run (algorithmic 3 x 64 MiB = 2.01e8)"}
+        if comm is None and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_gemm32(b, nb)
         if comm is None:
             # beside the parity mode (`value`): the same program with executor.fuse_gemm_reduction -- the K partial
             # products of a C tile accumulate in one fp32 buffer, no Temp tiles, no add_matrices tree

@@ -1001,9 +1001,11 @@ class HipBackend(object):
                 A, transpose_A = at, False
         self._use(sh, A, B, C, out)
         fn = self.lib.npw_dgemm if dt == _F64 else self.lib.npw_sgemm
+        t0 = self._tic("gemm", sh)
         _ffi.check(fn(b"T" if transpose_A else b"N", b"T" if transpose_B else b"N", m, n, ka, alpha, A.ptr, A.shape[1],
                       B.ptr, B.shape[1], beta, C.ptr if C is not None else None, n, out.ptr, n,
                       skip.ptr if skip is not None else None, sh), "gemm")
+        self._toc("gemm", sh, t0)
         if skip is not None:
             skip.streams.add(sh)
         self._produced(sh, out)
@@ -1358,8 +1360,11 @@ class HipBackend(object):
             if b is not None:
                 b.streams.add(sh)
         ptrs = (ctypes.c_void_p * count)(*[a.ptr for a in As])
+        # (the call joins its helper streams back into `sh` before it returns: the closing event covers all of it)
+        t0 = self._tic("geqrt_batched", sh)
         _ffi.check(self.lib.npw_dgeqrt_batched(count, m, n, ptrs, n, Vptr, n, m * n, Tbuf.ptr if want_t else None, n, n * n,
                                                Rbuf.ptr, n, n * n, ws.ptr, sh), "geqrt_batched")
+        self._toc("geqrt_batched", sh, t0, count)
         out = [(DeviceTile(Vbuf, (m, n), _F64, z * vb) if want_v else None, DeviceTile(Tbuf, (n, n), _F64, z * tb) if want_t else None,
                 DeviceTile(Rbuf, (n, n), _F64, z * rb)) for z in range(count)]
         self._produced(sh, *[t for triple in out for t in triple if t is not None])
@@ -1397,8 +1402,10 @@ class HipBackend(object):
                 b.streams.add(sh)
         p1 = (ctypes.c_void_p * count)(*[a.ptr for a, _ in pairs])
         p2 = (ctypes.c_void_p * count)(*[c.ptr for _, c in pairs])
+        t0 = self._tic("tpqrt_batched", sh)
         _ffi.check(self.lib.npw_dtpqrt_batched(count, n, p1, p2, n, Vptr, n, 2 * n * n, Tbuf.ptr if want_t else None, n, n * n,
                                                Rbuf.ptr, n, n * n, ws.ptr, sh), "tpqrt_batched")
+        self._toc("tpqrt_batched", sh, t0, count)
         out = [(DeviceTile(Vbuf, (2 * n, n), _F64, z * vb) if want_v else None, DeviceTile(Tbuf, (n, n), _F64, z * tb) if want_t else None,
                 DeviceTile(Rbuf, (n, n), _F64, z * tb)) for z in range(count)]
         self._produced(sh, *[t for triple in out for t in triple if t is not None])

@@ -34,6 +34,7 @@ import collections
 import ctypes
 import os
 import pickle
+import sys
 import time
 import traceback
 
@@ -572,6 +573,226 @@ def _stored_tile(bigm, idx):
 TIMEOUT_CHECK_EVERY = 32     # positions of the common task sequence between two collective looks at the clock
 
 
+class StallWatch(object):
+    """Self-diagnosis of a distributed run that stops making progress (the first contact with a real 8-GPU node is the
+    driver's, nobody is there to attach a debugger): the walk notes where it is -- position of the common task sequence,
+    task, what it is about to wait for -- and a daemon thread prints ONE report per stalled position to stderr once nothing
+    has moved for `report_s` seconds ($NUMPYWREN_AMD_DIST_STALL_REPORT_S, default 30; a position is milliseconds of host work):
+
+        [numpywren_amd.dist stall] rank 3/8 transport rccl: no progress for 30.0 s at position 412 of the common sequence,
+          task (5, {'i': 3, 'j': 9, 'k': 4}) = syrk, phase 'wait for own device (run-ahead bound)'; receives not complete: from
+          rank 1 S[4,9,4] (134217728 B), from rank 5 O[9,3]; last sends: O[9,3] -> [1, 2]; bytes sent / received ...
+
+    and, after `abort_s` seconds ($NUMPYWREN_AMD_DIST_STALL_ABORT_S, default 0 = never: the run's own `timeout` and the control
+    group's time limit end it), aborts the communicator (npw_comm_abort) so that device-side waits inside RCCL return and
+    the run fails loudly on every rank instead of hanging.  The counterpart of the progress poller of the reference's
+    experiments (cholesky_experiment.py:177-287 prints up / busy workers, flops and read / write GB/s every few seconds)."""
+
+    def __init__(self, comm, total, report_s=None, abort_s=None, out=None):
+        import threading
+        self.comm, self.total = comm, total
+        self.report_s = float(os.environ.get("NUMPYWREN_AMD_DIST_STALL_REPORT_S", "30") if report_s is None else report_s)
+        self.abort_s = float(os.environ.get("NUMPYWREN_AMD_DIST_STALL_ABORT_S", "0") if abort_s is None else abort_s)
+        self.out = out if out is not None else sys.stderr
+        self.position, self.task, self.kernel, self.phase = 0, None, "", "start"
+        self.last = time.time()
+        self.recv_log = collections.deque(maxlen=64)     # (src, key, nbytes, tile)
+        self.send_log = collections.deque(maxlen=8)      # (key, dsts)
+        self.reports = []
+        self.aborted = False
+        self._reported_at = None
+        self._stop = threading.Event()
+        self._thread = None
+        if self.report_s > 0:
+            self._thread = threading.Thread(target=self._loop, name="npw-dist-stall-watch", daemon=True)
+            self._thread.start()
+
+    def note(self, position=None, task=None, kernel=None, phase=None):
+        if position is not None:
+            self.position = position
+        if task is not None:
+            self.task = task
+        if kernel is not None:
+            self.kernel = kernel
+        if phase is not None:
+            self.phase = phase
+        self.last = time.time()
+
+    def received(self, src, key, nbytes, tile):
+        self.recv_log.append((src, key, nbytes, tile))
+
+    def sent(self, key, dsts):
+        self.send_log.append((key, list(dsts)))
+
+    @staticmethod
+    def _name(key):
+        return "?" if key is None else "{0}[{1}]".format(key[0], ",".join(str(int(x)) for x in key[1]))
+
+    def report(self, why=None):
+        """The report as a string (also kept in self.reports)."""
+        comm = self.comm
+        be = None
+        try:
+            be = get_backend()
+        except Exception:
+            pass
+        waiting = []
+        for src, key, nbytes, tile in list(self.recv_log):
+            ev = getattr(tile, "ready", None)
+            done = True
+            if ev is not None and be is not None and hasattr(be, "event_done"):
+                try:
+                    done = bool(be.event_done(ev))
+                except Exception:
+                    done = True
+            if not done:
+                waiting.append("from rank {0} {1} ({2} B)".format(src, self._name(key), nbytes))
+        idle = time.time() - self.last
+        text = ("[numpywren_amd.dist stall] rank {r}/{w} transport {t}: {why} at position {p} of {n} of the common sequence, task {task} = "
+                "{k}, phase '{ph}'; receives not complete: {wait}; last sends: {sends}; bytes sent / received {bs} / {br}".format(
+                    r=comm.rank, w=comm.world, t=comm.backend, why=why or "no progress for {0:.1f} s".format(idle), p=self.position,
+                    n=self.total, task=self.task, k=self.kernel, ph=self.phase,
+                    wait=("; ".join(waiting) if waiting else "none on record (peers waited on, if any: the ranks named in the phase)"),
+                    sends=("; ".join("{0} -> {1}".format(self._name(k), d) for k, d in self.send_log) or "none"),
+                    bs=comm.bytes_sent, br=comm.bytes_received))
+        self.reports.append(text)
+        try:
+            print(text, file=self.out, flush=True)
+        except Exception:
+            pass
+        return text
+
+    def _loop(self):
+        while not self._stop.wait(min(1.0, max(0.05, self.report_s / 4))):
+            idle = time.time() - self.last
+            if idle >= self.report_s and self._reported_at != (self.position, self.phase):
+                self._reported_at = (self.position, self.phase)
+                self.report()
+            if self.abort_s > 0 and idle >= self.abort_s and not self.aborted:
+                self.aborted = True
+                self.report("no progress for {0:.1f} s: aborting the communicator".format(idle))
+                try:
+                    self.comm.transport.abort_group()
+                except Exception:
+                    pass
+
+    def close(self):
+        self._stop.set()
+
+
+def link_calibration(comm, nbytes=128 << 20, repeats=3):
+    """What a tile transfer costs on THIS node, measured before the first timed step (bench.py --gpus N): the figure
+    profiles/predicted_scaling.json assumes (64 GB/s per direction) has never been measured by the builder.
+
+      * shift exchanges: for every distance d = 1 .. world - 1 all ranks at once send one `nbytes` tile to rank + d and
+        receive one from rank - d (ONE grouped launch: every rank drives one outgoing and one incoming link) -- GB/s per
+        direction per (rank, d), best of `repeats`;
+      * fan-out: rank 0 pushes the same tile to every other rank in one group (the panel tile of a Cholesky step going to
+        the owners of its consumers); the time until the last receiver has it, and the aggregate GB/s out of rank 0;
+      * all-to-all: every rank to every other rank in one group (the GEMM program's prologue).
+    A world of one exchanges with itself (a device-to-device copy through the transport: the fields exist, the numbers are
+    HBM's, and the line says so).  Timed with HIP events on the transport stream (RCCL) or the host clock (host transport).
+    Returns a dict on every rank (identical: the samples are gathered over the control group)."""
+    be = get_backend()
+    tr = comm.transport
+    rank, world = comm.rank, comm.world
+    n = max(8, int(nbytes) // 8)
+    src = be.zeros((n,), np.float64)
+    meta = TileMeta((n,), np.float64)
+    rccl = tr.name == "rccl"
+
+    def timed(post):
+        """seconds for one exchange described by post() (called between begin_group / end_group)"""
+        comm.barrier()
+        if rccl:
+            be.stream_sync(tr.stream)
+            e0 = be.new_event(timing=True)
+            be.record(e0, tr.stream)
+        t0 = time.time()
+        tr.begin_group()
+        got = post()
+        tr.end_group()
+        if rccl:
+            e1 = be.new_event(timing=True)
+            be.record(e1, tr.stream)
+            be.stream_sync(tr.stream)
+            dt = be.elapsed_ms(e0, e1) * 1e-3
+            be.recycle_event(e0)
+            be.recycle_event(e1)
+        else:
+            tr.flush()
+            dt = time.time() - t0
+        del got
+        return dt
+
+    def shift(d):
+        def post():
+            to, frm = (rank + d) % world, (rank - d) % world
+            # (blocking host transport: the lower rank of a pair sends first, so the pairs cannot lock up)
+            if rccl or rank < to:
+                tr.send(src, [to])
+                return tr.recv(frm, meta)
+            r = tr.recv(frm, meta)
+            tr.send(src, [to])
+            return r
+        return post
+
+    def self_exchange():
+        if rccl:
+            tr.send(src, [rank])
+            return tr.recv(rank, meta)
+        return be.copy(src)
+
+    samples = []
+    if world == 1:
+        best = min(timed(self_exchange) for _ in range(repeats))
+        samples.append({"rank": 0, "d": 0, "GBps": round(n * 8 / best / 1e9, 2)})
+    else:
+        for d in range(1, world):
+            if not rccl and world > 2 and d != 1 and d != world - 1:
+                continue                      # (host transport: a ring of blocking pairs is enough for a test box)
+            best = min(timed(shift(d)) for _ in range(repeats))
+            samples.append({"rank": rank, "d": d, "GBps": round(n * 8 / best / 1e9, 2)})
+    out = {"bytes": n * 8, "transport": tr.name, "what": ("self-exchange on one GPU: a device copy, not a link" if world == 1 else
+                                                          "GB/s per direction, one tile per (rank, distance), all ranks at once")}
+    fan = a2a = None
+    if world > 1 and rccl:
+        def fanout():
+            if rank == 0:
+                for dst in range(1, world):
+                    tr.send(src, [dst])
+                return None
+            return tr.recv(0, meta)
+        fan = min(timed(fanout) for _ in range(repeats))
+
+        def alltoall():
+            got = []
+            for dst in range(world):
+                if dst != rank:
+                    tr.send(src, [dst])
+            for s_ in range(world):
+                if s_ != rank:
+                    got.append(tr.recv(s_, meta))
+            return got
+        a2a = min(timed(alltoall) for _ in range(repeats))
+    gathered = [None] * world
+    if world > 1:
+        comm.dist.all_gather_object(gathered, {"samples": samples, "fan": fan, "a2a": a2a})
+    else:
+        gathered = [{"samples": samples, "fan": fan, "a2a": a2a}]
+    allv = [s_["GBps"] for g in gathered for s_ in g["samples"]]
+    out["xgmi_GBps"] = {"min": min(allv), "median": float(np.median(allv)), "max": max(allv)}
+    out["samples"] = [s_ for g in gathered for s_ in g["samples"]]
+    if world > 1 and rccl:
+        fmax = max(g["fan"] for g in gathered)
+        amax = max(g["a2a"] for g in gathered)
+        out["fanout_1_to_all_ms"] = round(fmax * 1e3, 3)
+        out["fanout_GBps_out_of_rank0"] = round((world - 1) * n * 8 / fmax / 1e9, 2)
+        out["all_to_all_ms"] = round(amax * 1e3, 3)
+        out["all_to_all_GBps_per_rank_out"] = round((world - 1) * n * 8 / amax / 1e9, 2)
+    return out
+
+
 def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, max_inflight=16):
     """Distributed counterpart of job_runner.lambdapack_run: every rank calls it with the same program.
 
@@ -619,6 +840,8 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
     sent0, recv0 = comm.bytes_sent, comm.bytes_received
     program._defer_success = True
     program._distributed_world = int(getattr(comm, "world", 1) or 1)    # (checkpoint.save refuses a run over several ranks)
+    watch = StallWatch(comm, len(compiled.tasks))
+    comm.stall_watch = watch
     try:
         # prologue: input tiles read by tasks that live on another rank than the tile itself (one grouped push per tile)
         moves = collections.OrderedDict()
@@ -640,9 +863,14 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
             for r, (home, consumers) in moves.items():
                 meta = metas.read(*r)
                 if rank == home:
+                    watch.note(phase="prologue: send {0} to {1}".format(StallWatch._name(r), list(consumers)))
                     comm.send_tile(_stored_tile(mats[r[0]], r[1]), consumers, known=meta is not None, meta=meta)
+                    watch.sent(r, consumers)
                 elif rank in consumers:
-                    mats[r[0]].put_tile(comm.recv_tile(home, meta, key=r), *r[1])
+                    watch.note(phase="prologue: receive {0} from rank {1}".format(StallWatch._name(r), home))
+                    got = comm.recv_tile(home, meta, key=r)
+                    watch.received(home, r, getattr(got, "nbytes", 0), got)
+                    mats[r[0]].put_tile(got, *r[1])
         except BaseException:
             comm.transport.abort_group()        # a partly posted group must not be launched (see RcclTransport.abort_group)
             raise
@@ -660,14 +888,20 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
             # leave them waiting inside RCCL for ever.  Every other decision in this loop is a function of the plan.
             if timeout is not None and step % TIMEOUT_CHECK_EVERY == TIMEOUT_CHECK_EVERY - 1:
                 t_b = time.time()
+                watch.note(position=step, phase="time-limit check: all_reduce over the control group (waits for EVERY rank to reach this position)")
                 late = comm.max_over_ranks(t_b - t_start) > timeout
                 blocked_s += time.time() - t_b
                 if late:
+                    # every rank says where it stands before the walk is left (the slowest rank's report names what it waited for)
+                    watch.report("time limit of {0} s exceeded (collective decision)".format(timeout))
                     program._enqueue(node)
                     timed_out = True
                     break
             step += 1
             e, v = node
+            watch.note(position=step, task=(int(e), dict(v)), kernel=getattr(compiled.kernel(e), "__name__", "task"), phase="walk")
+            if watch.aborted:
+                raise RuntimeError("lambdapack_run_distributed: the communicator was aborted after a stall (see the stall report on stderr)")
             # every rank forms the same group of ready tasks of one batchable kind and runs its own members of it as
             # one batched launch sequence; the exchange plan below is then walked in the common order
             group = [(e, v)]
@@ -695,8 +929,10 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
                     inflight.append(last)
                     if len(inflight) > max_inflight:
                         t_b = time.time()
+                        watch.note(phase="wait for own device (run-ahead bound): a kernel or a receive it depends on has not finished")
                         be.wait_tile(inflight.popleft())
                         blocked_s += time.time() - t_b
+                        watch.note(phase="walk")
             c4 = clock()
             # push the outputs to the remote consumers: both sides evaluate the same static plan here; the transfers of
             # one group of tasks (the right-hand sides of a batched solve, the nodes of a tree level) are one launch
@@ -709,10 +945,15 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
                         name, idx = task.writes[pos]
                         meta = out_metas[pos] if out_metas is not None else None
                         if rank == owner:
+                            watch.note(phase="send {0} to {1}".format(StallWatch._name((name, idx)), list(ranks)))
                             comm.send_tile(_stored_tile(mats[name], idx), ranks, known=meta is not None, meta=meta)
+                            watch.sent((name, idx), ranks)
                             ex.sent(name, idx)
                         elif rank in ranks:
-                            mats[name].put_tile(comm.recv_tile(owner, meta, key=(name, idx)), *idx)
+                            watch.note(phase="receive {0} from rank {1}".format(StallWatch._name((name, idx)), owner))
+                            got = comm.recv_tile(owner, meta, key=(name, idx))
+                            watch.received(owner, (name, idx), getattr(got, "nbytes", 0), got)
+                            mats[name].put_tile(got, *idx)
                     c5 = clock()
                     program.post_op(ge, gv, lp.PS.SUCCESS, None)
                     program.set_node_status(ge, gv, lp.NS.FINISHED)
@@ -725,8 +966,10 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
             split["exchange+post_op"] += clock() - c4
         t_walk_end = time.time()
         cpu_walk = time.thread_time() - cpu_start
+        watch.note(phase="drain: transport flush + device synchronise (every posted receive must arrive)")
         comm.flush()
         be.synchronize()
+        watch.note(phase="settle: control-group max over ranks")
         t_drained = time.time()
         ok = job_runner.settle_checks(program, be)
         # a failure on any rank fails the program everywhere
@@ -741,6 +984,7 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
         program._defer_success = False
         program.decr_up(1)
         ex.release_spill_plan()
+        watch.close()
     diag = {"rank": rank, "transport": comm.backend, "positions": step, "tasks_run_here": len(executed),
             # the common walk on the host, without the time it spent blocked in dist.py's OWN waits (the run-ahead bound, the
             # control group).  It still contains what the walk spent blocked INSIDE HIP calls: a launch returns late when the
@@ -752,7 +996,8 @@ def lambdapack_run_distributed(program, comm, pipeline_width=1, timeout=3600, ma
             "host_blocked_ms": round(1e3 * blocked_s, 3),
             # host time between the end of the walk and the device being drained: how far the device ran behind the host
             "drain_ms": round(1e3 * (t_drained - t_walk_end), 3),
-            "bytes_sent": comm.bytes_sent - sent0, "bytes_received": comm.bytes_received - recv0}
+            "bytes_sent": comm.bytes_sent - sent0, "bytes_received": comm.bytes_received - recv0,
+            "stall_reports": len(watch.reports)}
     split["exchange"] = split.pop("exchange+post_op", 0.0) - split["post_op"]
     diag["host_split_ms"] = {k: round(1e3 * v, 3) for k, v in sorted(split.items())}
     if diag_on:
