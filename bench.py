@@ -57,6 +57,22 @@ def _predicted_scaling(workload):
         return None
 
 
+def _predicted_at_link(workload, world, link_gbs):
+    """The model behind profiles/predicted_scaling.json (tools/predict_scaling.py) re-evaluated for THIS world size at the link
+    rate link_calibration() just measured on this node -- beside the table's own figure, which assumes 64 GB/s per direction.
+    Still a simulation: what it adds is that the one free parameter nobody had measured is now this node's."""
+    try:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("npw_predict_scaling", os.path.join(ROOT, "tools", "predict_scaling.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        row = mod.predict(workload, world, float(link_gbs))
+        return {"link_GBps_per_direction": round(float(link_gbs), 2), "gpus": world, "ms": row["ms"], "tflops": row["tflops"],
+                "source": "tools/predict_scaling.py predict() at the measured median link rate (a simulation, not a measurement)"}
+    except Exception as exc:       # the model must never cost a bench line
+        return {"error": repr(exc)}
+
+
 def _syrk_traffic():
     """(bytes per tile update, source) of the trailing-update kernel from the newest profiles/r*_bench_pmc.json: separate
     rocprofv3 --pmc passes of this command, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / tiles per dispatch (gfx950 reports wide
@@ -101,7 +117,10 @@ def job_identity(comm, world, rank):
     group, plus the size RCCL itself reports for the payload communicator."""
     import socket
     mine = {"rank": rank, "host": socket.gethostname(), "pid": os.getpid(), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
-            "device": None, "rccl_nranks": None}
+            "device": None, "rccl_nranks": None, "visible_devices": None,
+            # what narrows the device list of this process, if anything (a launcher that sets one GPU per rank AND leaves
+            # LOCAL_RANK counting up is fine -- the modulo below -- two ranks with the same list and the same LOCAL_RANK are not)
+            "env": {k: os.environ[k] for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES") if k in os.environ}}
     try:
         from numpywren_amd.device import hip_available
         if hip_available():
@@ -110,6 +129,7 @@ def job_identity(comm, world, rank):
             n = ctypes.c_int(0)
             _ffi.lib().npw_device_count(ctypes.byref(n))
             buf = ctypes.create_string_buffer(64)
+            mine["visible_devices"] = n.value
             if n.value > 0 and _ffi.lib().npw_device_pci_bus_id(mine["local_rank"] % n.value, buf, 64) == 0:
                 mine["device"] = buf.value.decode()
     except Exception:
@@ -499,7 +519,7 @@ def tsqr_roofline(times, b, r_only):
     t_hbm = bytes32 / 6.3e12 * 1e3 if bytes32 else None
     out = {"bound": "hbm" if (t_hbm is not None and t_hbm > t_mfma) else "mfma",
            "kernel": "npw_dgeqrt_batched x32 (kernels.qr_factor on 32 leaves of 4096^2: panel chain + three levels of block reflectors; "
-                     "dominant device kernels by rocprof share: gemm_kernel<double,128,128,16,true,true,false,3> -- the rank-256 far update -- "
+                     "dominant device kernels by rocprof share: gemm_kernel<double,128,128,16,true,true,false,0,2> -- the rank-256 far update -- "
                      "and gemm_kernel<double,128,256,16,false,false,false,0,4> -- its X^T = W2^T V product; profiles/r06_qr_batched32*_kernel_stats.csv)",
            "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
            "launches": len(leaf), "avg_ms": round(avg_ms, 4), "avg_ms_is": "per leaf tile (a call of 32 tiles / 32)",
@@ -512,6 +532,19 @@ def tsqr_roofline(times, b, r_only):
         out["tree_nodes"] = {"launches": len(node), "avg_ms": round(float(np.mean(node)), 4),
                              "what": "npw_dtpqrt_batched, per node (two stacked 4096^2 triangles)"}
     return out
+
+
+def first_contact(comm, args):
+    """N > 1 (or the forced distributed path): the all-pairs link calibration of dist.link_calibration, before the first timed
+    step and outside every timed region.  The transfer size follows the tile (128 MiB for the 4096^2 fp64 tile)."""
+    from numpywren_amd import dist
+    nbytes = min(128 << 20, max(1 << 20, args.tile * args.tile * 8))
+    try:
+        return dist.link_calibration(comm, nbytes=nbytes)
+    except Exception as exc:
+        if comm.rank == 0:
+            print(f"[bench] link calibration failed: {exc!r}", file=sys.stderr)
+        return None
 
 
 def main():
@@ -580,6 +613,7 @@ def main():
     chain_cus = int(npw_config.default()["executor"].get("chain_cus", 0) or 0) if (world == 1 and args.streams == 1) else 0
     run = Runner(be, comm, args.streams, args.priority_stream)
     anchor = None
+    calib = None     # N > 1: dist.link_calibration's result (first_contact), measured before the first timed step
     par = "1 gpu" if world == 1 else (f"{world} gpus, one process each, tiles 2-D block-cyclic, " + (
         "RCCL p2p panel exchange (npw_comm_*)" if comm is not None and comm.backend == "rccl" else
         "payloads staged through the host over the control group (ranks share a GPU: not a production transport)"))
@@ -599,6 +633,7 @@ def main():
                                     lambda Xa: alg_wrappers.cholesky(Xa), n ** 3 / 3.0)
         if comm is not None:
             comm.open_transport()
+            calib = first_contact(comm, args)
         X = build_input(be, nb, b, f"bench_chol_{n}_{b}", rank, world, owner)
         # inside the timed region only the roofline kernel is bracketed with events (an event record costs ~4 us of
         # stream time); the other kinds are timed in two extra steps after it, for `kernel_ms`
@@ -692,6 +727,7 @@ def main():
                                     lambda Xa: alg_wrappers.tsqr(Xa), 2.0 * m * b * b - 2.0 * b ** 3 / 3, r_only=r_only)
         if comm is not None:
             comm.open_transport()
+            calib = first_contact(comm, args)
         if comm is not None:
             from numpywren_amd import dist
             comm.ownership = dist.tsqr_ownership(world, leaves)
@@ -745,6 +781,7 @@ def main():
         if comm is not None:
             from numpywren_amd import dist
             comm.open_transport()
+            calib = first_contact(comm, args)
             comm.ownership = dist.gemm_ownership(world)
         A = BigMatrix(f"bench_gA_{n}", shape=(n, n), shard_sizes=(b, b), dtype=np.float32)
         B = BigMatrix(f"bench_gB_{n}", shape=(n, n), shard_sizes=(b, b), dtype=np.float32)
@@ -795,6 +832,13 @@ def main():
     line.update(step_stats(run_step_ms, line["ms_per_step"]))
     if comm is not None:
         line["config"]["transport"] = comm.backend
+        if calib is not None:
+            # measured before the first timed step, outside the timed region: what one 128 MiB tile costs on this node's links
+            line["config"]["xgmi_GBps"] = calib["xgmi_GBps"]
+            line["config"]["link_calibration"] = {k: v for k, v in calib.items() if k not in ("xgmi_GBps", "samples")}
+            line["config"]["link_calibration"]["samples"] = calib["samples"][:64]
+            if world > 1 and rank == 0:
+                line["config"]["predicted_at_measured_link"] = _predicted_at_link(args.workload, world, calib["xgmi_GBps"]["median"])
         # who ran this: the ranks that joined the control group, the device each one bound, and the size RCCL itself
         # reports for the payload communicator -- a line is only printed when they all equal --gpus
         joined = job_identity(comm, world, rank)
@@ -834,7 +878,10 @@ def main():
         if world > 1 and comm.backend != "rccl" and not os.environ.get("NUMPYWREN_AMD_DIST_BACKEND"):
             raise SystemExit("bench.py --gpus %d: the ranks ended up on the host-staged transport (%s) -- tiles would cross "
                              "PCIe and host memory instead of xGMI; a number from this run would mean nothing.  Set "
-                             "NUMPYWREN_AMD_DIST_BACKEND=gloo to force it knowingly." % (world, comm.backend))
+                             "NUMPYWREN_AMD_DIST_BACKEND=gloo to force it knowingly.  Who joined (rank, LOCAL_RANK, devices this "
+                             "process sees, the *_VISIBLE_DEVICES it was given, PCI bus id of the device it bound): %s"
+                             % (world, comm.backend, [(j["rank"], j["local_rank"], j["visible_devices"], j["env"], j["device"])
+                                                      for j in joined if j]))
     if rank == 0:
         print(json.dumps(line))
     if comm is not None:

@@ -425,7 +425,17 @@ def init_process_group(backend=None, open_transport=True):
             ids = [mine]
         use_rccl = all(i is not None for i in ids) and len(set(ids)) == world
         if not use_rccl and want in ("rccl", "nccl"):
-            raise RuntimeError(f"RCCL transport needs one GPU per rank; the ranks sit on {ids}")
+            raise RuntimeError(f"RCCL transport needs one GPU per rank; the ranks sit on {ids} (rank {rank}: LOCAL_RANK="
+                               f"{os.environ.get('LOCAL_RANK')}, HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')}, "
+                               f"ROCR_VISIBLE_DEVICES={os.environ.get('ROCR_VISIBLE_DEVICES')})")
+        if hip_available() and mine is not None:
+            # LOCAL_RANK beyond the devices this process sees is bound by modulo (HipBackend): legitimate when the launcher
+            # gives every rank its own one-device list, a doubled-up GPU otherwise -- the bus-id comparison above decides
+            # which, this only says so early and by name
+            lr, nvis = int(os.environ.get("LOCAL_RANK", "0")), n.value
+            if lr >= nvis > 1:
+                import warnings
+                warnings.warn(f"numpywren_amd.dist: rank {rank} has LOCAL_RANK={lr} but sees {nvis} devices; it binds device {lr % nvis}")
         if not use_rccl and mine is not None and rank == 0:
             import warnings
             warnings.warn("numpywren_amd.dist: ranks share a GPU (PCI bus ids {0}): tiles are staged through host memory "

@@ -104,6 +104,11 @@ def test_bench_distributed_path_on_one_gpu():
     # the evidence of who ran it: one rank joined, RCCL itself reports a communicator of one, one PCI device
     assert line["config"]["ranks_joined"] == 1 == line["config"]["rccl_nranks"] and len(line["config"]["devices"]) == 1
     assert line["config"]["devices"][0] and len(line["step_ms"]) == 1
+    # first contact: the link calibration ran before the timed step (a world of one exchanges with itself over RCCL)
+    cal, x = line["config"]["link_calibration"], line["config"]["xgmi_GBps"]
+    assert cal["transport"] == "rccl" and "self-exchange" in cal["what"] and 0 < x["min"] <= x["median"] <= x["max"]
+    assert cal["samples"] == [{"rank": 0, "d": 0, "GBps": x["min"]}]
+    assert line["per_rank"][0]["timed_step"]["stall_reports"] == 0
 
 
 @pytest.mark.gpu
@@ -127,6 +132,11 @@ def test_bench_two_ranks_on_one_gpu(workload, extra, port):
     for k, t in REQUIRED.items():
         assert k in line and isinstance(line[k], t), k
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["transport"] == "host"
+    # the new first-contact fields (host-staged numbers here: two ranks share the GPU) and the model re-evaluated at them
+    x = line["config"]["xgmi_GBps"]
+    assert 0 < x["min"] <= x["median"] <= x["max"] and line["config"]["link_calibration"]["transport"] == "host"
+    pred = line["config"]["predicted_at_measured_link"]
+    assert pred["gpus"] == 2 and pred["tflops"] > 0 and abs(pred["link_GBps_per_direction"] - x["median"]) < 0.01, pred
     # every N > 1 line explains itself: per rank the host's walk, its blocked time, how far the device ran behind, the bytes
     # moved (last timed step) and, from one extra step with executor.task_timers, device time by kernel and transport time
     assert len(line["per_rank"]) == 2

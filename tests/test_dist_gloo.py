@@ -246,6 +246,56 @@ def _worker(rank, world, port, scenario, outdir):
         got = dist.gather_matrix(meta["outputs"][0], comm)
         if rank == 0:
             np.testing.assert_allclose(got, np.linalg.cholesky(A), rtol=1e-10, atol=1e-10)
+    elif scenario == "stalled_rank":
+        # a rank that stops making progress (here: rank 1 sleeps 1.5 s inside one task) must leave a
+        # report on EVERY rank that is held up by it -- who, at which position of the common sequence, in which task, waiting
+        # for which peer -- instead of a silent hang.  Nothing is aborted (abort_s = 0): the run completes once rank 1 wakes up.
+        import io
+        import time as _time
+        os.environ["NUMPYWREN_AMD_DIST_STALL_REPORT_S"] = "0.3"
+        # the link calibration first (host transport on this box: blocking pairs over the control group)
+        calib = dist.link_calibration(comm, nbytes=1 << 16, repeats=2)
+        assert calib["transport"] == "host" and calib["xgmi_GBps"]["min"] > 0 and calib["xgmi_GBps"]["min"] <= calib["xgmi_GBps"]["median"] <= calib["xgmi_GBps"]["max"]
+        assert len(calib["samples"]) == world * (world - 1 if world == 2 else 2) and {s["rank"] for s in calib["samples"]} == set(range(world))
+        rng = np.random.default_rng(6)
+        nb, b = 6, 4
+        G = rng.standard_normal((nb * b, nb * b))
+        A = G @ G.T + nb * b * np.eye(nb * b)
+        X = BigMatrix("chol_stall", shape=A.shape, shard_sizes=(b, b))
+        scatter_owned(X, A, "I")
+        program, meta = alg_wrappers.cholesky(X)
+        program.start()
+        from numpywren_amd import job_runner
+        real = job_runner.LambdaPackExecutor.run_task
+        calls = {"n": 0}
+
+        def stall(self, e, v, stream=None):
+            calls["n"] += 1
+            if rank == 1 and calls["n"] == 3:
+                _time.sleep(1.5)
+            return real(self, e, v, stream=stream)
+        job_runner.LambdaPackExecutor.run_task = stall
+        err, sys.stderr = sys.stderr, io.StringIO()
+        try:
+            res = dist.lambdapack_run_distributed(program, comm, timeout=None)
+            printed = sys.stderr.getvalue()
+        finally:
+            sys.stderr = err
+            job_runner.LambdaPackExecutor.run_task = real
+        assert program.program_status() == lp.PS.SUCCESS, program.exceptions
+        reports = comm.stall_watch.reports
+        counts = [None] * world
+        comm.dist.all_gather_object(counts, len(reports))
+        assert counts[0] >= 1, counts                     # rank 0 waited for rank 1 and said so
+        if rank == 0:
+            text = reports[0]
+            assert text in printed and res["diag"]["stall_reports"] == len(reports)
+            assert "rank 0/2" in text and "position" in text and "task (" in text and "no progress for" in text
+            # the peer it was held up by: a receive from rank 1, or (blocking host transport) a send rank 1 has not taken yet
+            assert "from rank 1" in text or "to [1]" in text, text
+        got = dist.gather_matrix(meta["outputs"][0], comm)
+        if rank == 0:
+            np.testing.assert_allclose(got, np.linalg.cholesky(A), rtol=1e-10, atol=1e-10)
     elif scenario == "not_pd":
         A = np.eye(32)
         A[20, 20] = -1.0
@@ -300,6 +350,11 @@ def test_gemm_sharded(tmp_path):
 def test_time_limit_is_a_collective_decision(tmp_path):
     """one slow rank, a short limit -- every rank stops at the same position, then resumes."""
     _spawn(2, "slow_rank", tmp_path)
+
+
+def test_a_stalled_rank_is_reported_by_the_ranks_it_holds_up(tmp_path):
+    """the per-rank stall report (dist.StallWatch) and the link calibration's fields on two gloo ranks."""
+    _spawn(2, "stalled_rank", tmp_path)
 
 
 def test_failure_reaches_every_rank(tmp_path):

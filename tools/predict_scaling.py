@@ -37,7 +37,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["NUMPYWREN_AMD_STORE"] = "host"
+if __name__ == "__main__":
+    os.environ["NUMPYWREN_AMD_STORE"] = "host"     # (not when bench.py imports the model: no tile is stored by it anyway)
 
 # ---- measured single-GPU inputs (ms); sources in profiles/r04_*.md ----------------------------------------------------
 KERNEL_MS_1GPU = {"chol": 1.48, "trsm": 1.10, "syrk": 1.89, "syrk_sym": 1.08}          # one stream + chain partition
@@ -207,6 +208,16 @@ def predict_gemm(world, nb, link_gbs):
     n = nb * 4096
     return {"gpus": world, "grid": f"{pr}x{pc}", "ms": round(ms, 1), "tflops": round(2.0 * n ** 3 / (ms * 1e-3) / 1e12, 1),
             "prologue_ms": round(prologue, 1), "compute_ms": round(compute, 1), "GB_moved": round(sum(link.values()) / 1e9, 1)}
+
+
+def predict(workload, world, link_gbs):
+    """One row of the table for `workload` on `world` GPUs at `link_gbs` GB/s per direction (bench.py re-evaluates the model with
+    the link rate it measured on the node it runs on)."""
+    if workload == "chol":
+        return simulate_cholesky(world, 16, link_gbs, KERNEL_MS_1GPU if world == 1 else KERNEL_MS_3STREAMS, HOST_US_PER_POSITION)
+    if workload == "tsqr":
+        return predict_tsqr(world, 256, link_gbs)
+    return predict_gemm(world, 8, link_gbs)
 
 
 if __name__ == "__main__":
