@@ -178,46 +178,44 @@ class BigMatrix(object):
     def true_block_idx(self, *block_idx):
         return block_idx
 
+    def _axis_ranges(self, ax):
+        """[(start, end)] of the tiles along axis `ax`: tile t covers [t s, min((t + 1) s, n)) for
+        t = 0 .. ceil(n / s) - 1 -- full shards, the last one cut at the matrix edge.  (A zero-length axis has no tile; the
+        reference indexes [-1] of an empty list there: the same IndexError.)"""
+        n, s = int(self.shape[ax]), int(self.shard_sizes[ax])
+        count = -(-n // s)
+        if count == 0:
+            raise IndexError("list index out of range")
+        return [(t * s, min((t + 1) * s, n)) for t in range(count)]
+
     def _blocks(self, axis=None):
-        all_blocks = []
-        for i in range(len(self.shape)):
-            n, s = self.shape[i], self.shard_sizes[i]
-            axis_blocks = [(j, j + s) for j in range(0, n, s)]
-            if axis_blocks[-1][1] > n:
-                axis_blocks.pop()
-            if axis_blocks[-1][1] < n:
-                axis_blocks.append((axis_blocks[-1][1], n))
-            all_blocks.append(axis_blocks)
-        if axis is None:
-            return list(itertools.product(*all_blocks))
-        elif type(axis) is not int:
+        """Tile extents: every axis' ranges (axis=None: their C-order product) -- reference matrix.py:426-443."""
+        if axis is not None and type(axis) is not int:
             raise Exception("Axis must be an integer.")
-        return all_blocks[axis]
+        per_axis = [self._axis_ranges(ax) for ax in range(len(self.shape))]
+        return list(itertools.product(*per_axis)) if axis is None else per_axis[axis]
 
     def _block_idxs(self, axis=None):
-        idxs = [list(range(len(self._blocks(axis=i)))) for i in range(len(self.shape))]
-        if axis is None:
-            return list(itertools.product(*idxs))
-        elif type(axis) != int:
+        """Tile indices, same convention (reference matrix.py:448-455; its message differs from _blocks' by design of neither)."""
+        if axis is not None and type(axis) != int:
             raise Exception("Axis must be integer")
-        return idxs[axis]
+        counts = [len(self._axis_ranges(ax)) for ax in range(len(self.shape))]
+        if axis is None:
+            return list(itertools.product(*[range(c) for c in counts]))
+        return list(range(counts[axis]))
 
     def _register_parent(self, parent_fn):
         self.parent_fn = parent_fn
 
     def __block_idx_to_real_idx__(self, block_idx):
-        out = []
-        for i in range(len(self.shape)):
-            start = block_idx[i] * self.shard_sizes[i]
-            end = min(start + self.shard_sizes[i], self.shape[i])
-            out.append((start, end))
-        return tuple(out)
+        """((start, end), ...) of tile `block_idx`; indices beyond the nominal grid are allowed (safe=False matrices) and get
+        an empty or inverted range exactly as in the reference (matrix.py:480-488)."""
+        return tuple((int(t) * s, min((int(t) + 1) * s, n)) for t, s, n in zip(block_idx, self.shard_sizes, self.shape))
 
     def __get_matrix_shard_key__(self, real_idxs):
-        key_string = ""
-        for ((sidx, eidx), shard_size) in zip(real_idxs, self.shard_sizes):
-            key_string += "{0}_{1}_{2}_".format(sidx, eidx, shard_size)
-        return os.path.join(self.key_base, key_string)
+        """Object name of a tile: "<start>_<end>_<shard>_" per axis under the matrix' key base (matrix.py:457-464)."""
+        name = "".join("%d_%d_%d_" % (lo, hi, sz) for (lo, hi), sz in zip(real_idxs, self.shard_sizes))
+        return os.path.join(self.key_base, name)
 
     def __shard_idx_to_key__(self, block_idx):
         # memoised per (shape, shard_sizes, key_base): the executor asks for the same few hundred keys on every read and
