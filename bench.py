@@ -558,8 +558,12 @@ def first_contact(comm, args):
     try:
         return dist.link_calibration(comm, nbytes=nbytes)
     except Exception as exc:
-        if comm.rank == 0:
-            print(f"[bench] link calibration failed: {exc!r}", file=sys.stderr)
+        print(f"[bench] rank {comm.rank}: link calibration failed: {exc!r}", file=sys.stderr, flush=True)
+        watch = getattr(comm, "stall_watch", None)
+        if "aborted" in repr(exc):
+            # the communicator is gone: a timed run on it would only hang where the calibration did
+            raise SystemExit(f"bench.py --gpus {comm.world}: the first payload over this node's links did not complete -- see the "
+                             f"stall report of every rank above")
         return None
 
 

@@ -710,10 +710,16 @@ def link_calibration(comm, nbytes=128 << 20, repeats=3):
     src = be.zeros((n,), np.float64)
     meta = TileMeta((n,), np.float64)
     rccl = tr.name == "rccl"
+    # the calibration is the first payload that ever crosses this node's links: if it hangs, say where, and (RCCL) abort after
+    # $NUMPYWREN_AMD_DIST_CALIB_ABORT_S (default 180 s) so that the job ends with an error instead of sitting in a stream wait
+    watch = StallWatch(comm, 0, abort_s=float(os.environ.get("NUMPYWREN_AMD_DIST_CALIB_ABORT_S", "180")) if rccl else 0.0)
+    what = ["start"]
 
     def timed(post):
         """seconds for one exchange described by post() (called between begin_group / end_group)"""
+        watch.note(phase="link calibration: " + what[0] + " (control-group barrier)")
         comm.barrier()
+        watch.note(phase="link calibration: " + what[0] + " (payload in flight)")
         if rccl:
             be.stream_sync(tr.stream)
             e0 = be.new_event(timing=True)
@@ -755,12 +761,14 @@ def link_calibration(comm, nbytes=128 << 20, repeats=3):
 
     samples = []
     if world == 1:
+        what[0] = "self-exchange"
         best = min(timed(self_exchange) for _ in range(repeats))
         samples.append({"rank": 0, "d": 0, "GBps": round(n * 8 / best / 1e9, 2)})
     else:
         for d in range(1, world):
             if not rccl and world > 2 and d != 1 and d != world - 1:
                 continue                      # (host transport: a ring of blocking pairs is enough for a test box)
+            what[0] = "shift by %d: send to rank %d, receive from rank %d" % (d, (rank + d) % world, (rank - d) % world)
             best = min(timed(shift(d)) for _ in range(repeats))
             samples.append({"rank": rank, "d": d, "GBps": round(n * 8 / best / 1e9, 2)})
     out = {"bytes": n * 8, "transport": tr.name, "what": ("self-exchange on one GPU: a device copy, not a link" if world == 1 else
@@ -773,6 +781,7 @@ def link_calibration(comm, nbytes=128 << 20, repeats=3):
                     tr.send(src, [dst])
                 return None
             return tr.recv(0, meta)
+        what[0] = "fan-out from rank 0 to every rank"
         fan = min(timed(fanout) for _ in range(repeats))
 
         def alltoall():
@@ -784,7 +793,12 @@ def link_calibration(comm, nbytes=128 << 20, repeats=3):
                 if s_ != rank:
                     got.append(tr.recv(s_, meta))
             return got
+        what[0] = "all-to-all"
         a2a = min(timed(alltoall) for _ in range(repeats))
+    watch.note(phase="link calibration: gathering the samples over the control group")
+    watch.close()
+    if watch.aborted:
+        raise RuntimeError("link calibration: no progress for %.0f s, communicator aborted (%s)" % (watch.abort_s, watch.reports[-1] if watch.reports else ""))
     gathered = [None] * world
     if world > 1:
         comm.dist.all_gather_object(gathered, {"samples": samples, "fan": fan, "a2a": a2a})
