@@ -172,7 +172,7 @@ __device__ inline void block_to_tile_tri(int tiles, bool spread, int& tm, int& t
     tn = id - row * (row + 1) / 2;
 }
 
-// TAG only gives the kernel a distinct symbol: TAG 1 = the tile-level trailing update issued by
+// TAG gives the kernel a distinct symbol (TAG 4 also a schedule: see launch()): TAG 1 = the tile-level trailing update issued by
 // npw_dgemm_nt_sub (kernels.syrk), so profilers report it separately from the many smaller GEMMs that
 // trsm / potrf / geqrt run through the same tiling; TAG 2 = its symmetric form (X == Y, lower tiles only).
 // NW = waves along n: 2 (4 waves as 2 x 2, two workgroups per CU) or 4 (8 waves as 2 x 4, ONE workgroup per CU holding a
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(128 * NW, 2) void gemm_kernel(const GemmParams<T> p
         load_tiles(0);
         store_tiles(0);
         __syncthreads();
-        if constexpr (A_KC && B_KC && BM == 128 && BN == 128) {
+        if constexpr ((A_KC && B_KC && BM == 128 && BN == 128) || TAG == 4) {
             // The LDS stores of the next k-tile are spread between the MFMAs of the LAST step group instead of leaving
             // as a burst in front of the barrier.  Measured on the 4096^3 trailing update (tools/syrk_time.py): the
             // loop without the stores runs at 74.7 TFLOP/s -- the bare-MFMA ceiling; the barrier costs nothing -- with
@@ -465,12 +465,14 @@ __global__ __launch_bounds__(128 * NW, 2) void gemm_kernel(const GemmParams<T> p
             constexpr int HALF = GROUPS * MF / 2;              // the stores go between the MFMAs of the second half
             constexpr int PER = HALF / NST;
             static_assert(PER >= 1 && GROUPS <= 2, "store interleave: unexpected tile geometry");
+            // LDS reads per fragment group: one 16-byte read per fragment for k-contiguous operands, VEC 8-byte reads otherwise
+            constexpr int FRAGS = (A_KC ? TM : TM * VEC) + (B_KC ? TN : TN * VEC);
             for (int kt = 0; kt + 1 < nk; ++kt) {
                 const int cur = kt & 1;
                 load_tiles(kt + 1);
                 compute(cur);
                 store_tiles(cur ^ 1);
-                __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);       // fragments of the first group
+                __builtin_amdgcn_sched_group_barrier(0x100, FRAGS, 0);       // fragments of the first group
                 // first half of the MFMAs, the global loads of the next k-tile between them (one per PER MFMAs: as a burst
                 // at the top of the iteration they cost 1.5 %; spread, the wave's memory instructions never queue)
 #pragma unroll
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(128 * NW, 2) void gemm_kernel(const GemmParams<T> p
                     __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
-                if constexpr (GROUPS == 2) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+                if constexpr (GROUPS == 2) __builtin_amdgcn_sched_group_barrier(0x100, FRAGS, 0);
 #pragma unroll
                 for (int g = 0; g < NST; ++g) {
                     __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
@@ -639,6 +641,24 @@ int launch(const GemmParams<T>& p, hipStream_t stream) {
             // (tag 2 with diag_ws: the diagonal blocks' k chunks ride behind the tile pairs)
             const int extra = (p.tag == 2 && p.diag_ws != nullptr) ? p.tiles_m * p.diag_split : 0;
             hipLaunchKernelGGL(tagged, dim3(nwg + extra, nsplit, nbatch), dim3(256), smem, stream, p);
+            NPW_LAUNCH_CHECK();
+            return NPW_OK;
+        }
+    }
+    if constexpr (sizeof(T) == 8 && NW == 4 && BN == 256 && !A_KC && !B_KC && !EDGE) {
+        // TAG 4 = the same kernel with the pinned load / store interleave of the 128 x 128 N / T tiling (its fragment groups are
+        // 2 x (TM + TN) 8-byte LDS reads instead of TM + TN 16-byte ones).  Round 6, same-box A/B on a batch of 32 factorisations:
+        // every launch on one stream 91.8 -> 90.3 ms (the product itself ~7 % faster), four streams 76.0 / 76.4 -> 75.7 / 75.9
+        // R only, 103.2 / 103.7 -> 102.6 / 102.7 with T; the same sums in the same order.  $NPW_GEMM_WIDE_PINNED=0: the plain loop.
+        static const bool pinned = [] { const char* e = getenv("NPW_GEMM_WIDE_PINNED"); return e == nullptr || atoi(e) != 0; }();
+        if (pinned) {
+            auto k4 = gemm_kernel<T, BM, BN, BK, A_KC, B_KC, EDGE, 4, NW>;
+            static thread_local bool a4 = false;
+            if (!a4) {
+                NPW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                a4 = true;
+            }
+            hipLaunchKernelGGL(k4, dim3(nwg, nsplit, nbatch), dim3(128 * NW), smem, stream, p);
             NPW_LAUNCH_CHECK();
             return NPW_OK;
         }
