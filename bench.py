@@ -270,11 +270,12 @@ def _best_blas_threads(oracle, rng):
     return max(sweep, key=sweep.get), sweep
 
 
-def cpu_baseline_tsqr(b, leaves_total, sample_leaves=4):
+def cpu_baseline_tsqr(b, leaves_total, sample_leaves=2):
     """the oracle's TSQR (oracle.tsqr: LAPACK DGEQRT through SciPy on every leaf and tree node, the
     reference's fast_qr restated) on a `sample_leaves`-leaf, b-wide slice of the same input, all host cores, scaled to the
-    full problem by algorithmic flops (2 m n^2 - 2 n^3 / 3).  Four leaves, not the survey's 16 - 32: SciPy's DGEQRT takes ~3 s per
-    4096^2 leaf and ~6 s per 8192 x 4096 node on these hosts (8 leaves: 65 s), and the contract bounds the sample at 10 - 30 s.  kind = "port": the reference's own LAPACK module is an f2py
+    full problem by algorithmic flops (2 m n^2 - 2 n^3 / 3).  Two leaves and their tree node, not the survey's 16 - 32: SciPy's DGEQRT
+    takes 3 - 5 s per 4096^2 leaf and 6 - 10 s per 8192 x 4096 node on these hosts (8 leaves: 65 s, 4 leaves: 28 - 40 s), and the
+    contract bounds the sample at 10 - 30 s.  kind = "port": the reference's own LAPACK module is an f2py
     build it downloads at run time (kernels.py:12-40) and is not in its tree."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import npw_oracle as oracle
