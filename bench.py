@@ -589,6 +589,9 @@ def main():
     ap.add_argument("--no-anchor", action="store_true", help="N > 1: skip rank 0's one-GPU run of the same problem (config.one_gpu_anchor)")
     ap.add_argument("--dry-run", action="store_true", help="start / join the ranks, print who joined as one JSON line, do no GPU work")
     args = ap.parse_args()
+    # dmabuf IPC between the ranks' processes (what RCCL needs on this driver stack); read by the HSA runtime when it starts, so it
+    # has to be in the environment before the first HIP call of this process -- a launcher normally exports it, this is the net
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

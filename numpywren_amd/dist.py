@@ -391,6 +391,8 @@ def init_process_group(backend=None, open_transport=True):
     through the host over the control group (CPU tests; several ranks on the one GPU of a test box)."""
     import datetime
     import torch.distributed as dist
+    # (dmabuf IPC for RCCL between processes: only effective if no HIP call has been made in this process yet; bench.py sets it first thing)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
