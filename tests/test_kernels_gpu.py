@@ -199,6 +199,28 @@ def test_add_matrices_promotes_to_float64():
     assert np.array_equal(kernels.add_matrices(*many), oracle.add_matrices(*many))
 
 
+def test_add_matrices_skips_the_shared_zero_tile_bit_for_bit():
+    """The padding operands of the GEMM program's add tree are reads of never-written constant_zeros tiles: the backend's shared
+    zero tile, which add_n does not read.  Same bits as the reference's np.zeros(shape) += a, signed zeros included."""
+    from numpywren_amd.device import get_backend
+    be = get_backend()
+    rng = np.random.default_rng(61)
+    a = rng.standard_normal((48, 40))
+    a[0, :5] = -0.0
+    a[1, :5] = 0.0
+    b = -a.copy()                       # exact cancellation: +0.0 everywhere in a + b
+    z = be.shared_zeros((48, 40))
+    zeros = np.zeros((48, 40))
+    for ops, ref in (((a, None), (a, zeros)), ((None, a, None, None), (zeros, a, zeros, zeros)), ((a, None, b), (a, zeros, b)),
+                     ((None, None), (zeros, zeros))):
+        tiles = [z if o is None else be.to_device(o) for o in ops]
+        got = be.to_host(kernels.add_matrices(*tiles))
+        want = oracle.add_matrices(*ref)
+        assert got.dtype == np.float64 and np.array_equal(got, want)
+        assert np.array_equal(np.signbit(got), np.signbit(want))
+    assert not be.to_host(z).any()      # the shared tile itself is untouched
+
+
 @pytest.mark.parametrize("m,n", [(8, 8), (16, 8), (64, 64), (96, 32), (128, 128), (200, 67), (256, 128)])
 def test_qr_factor_vs_oracle(m, n):
     rng = np.random.default_rng(m + n)
