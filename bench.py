@@ -617,8 +617,11 @@ def main():
     os.environ.pop("NUMPYWREN_AMD_STORE", None)
     if args.streams <= 0:
         # (tsqr: one stream -- a batch of 32 factorisations fills the chip by itself; two batches side by side only fight for
-        #  workgroup slots: 1716 ms with one stream, 1940 with two on the round-3 build, gpurun_out/r03i)
-        args.streams = 1 if world == 1 else 3
+        #  workgroup slots: 1716 ms with one stream, 1940 with two on the round-3 build, gpurun_out/r03i.  gemm32: two -- the
+        #  add_matrices tree of the reference's program is HBM-bound and its kernels need a dozen registers, so they run BESIDE
+        #  the products of the other stream instead of between them: round 6, same box, 128.2 / 131.3 TFLOP/s with one stream,
+        #  136.8 / 136.1 with two, 136.4 / 135.7 with three)
+        args.streams = (2 if args.workload == "gemm32" else 1) if world == 1 else 3
 
     from numpywren_amd import alg_wrappers
     from numpywren_amd.device import get_backend
@@ -817,7 +820,8 @@ def main():
                     B.put_tile(be.convert(be.fill_random((b, b), 12, i * b, j * b), np.float32), i, j)
         be.synchronize()
         elapsed, meta = run.timed(lambda: alg_wrappers.gemm(A, B), args.steps, args.warmup, timers=("gemm",))
-        gemm_times = be.collect_kernel_times().get("gemm", []) if comm is None else []
+        gemm_iv = be.collect_kernel_times(intervals=True).get("gemm", []) if comm is None else []
+        gemm_times = [e - s0 for s0, e, _ in gemm_iv]
         run_step_ms = run.step_ms
         value = args.steps * 2.0 * n ** 3 / elapsed / 1e12
         line = {"metric": "achieved fp32 TFLOP/s, N x N GEMM program (2 N^3 / wall)", "value": round(value, 3),
@@ -829,12 +833,27 @@ def main():
                            "parallelism": par, "pct_fp32_mfma_peak": round(100 * value / (157.3 * args.gpus), 2)}}
         if comm is None and gemm_times:
             avg_ms = float(np.mean(gemm_times))
-            achieved = 2.0 * b ** 3 / (avg_ms * 1e-3) / 1e12
+            # With two executor streams (the default for this workload: the HBM-bound add_matrices tree then runs beside the
+            # products instead of between them) two products share the chip and each takes twice as long: the kernel's rate is
+            # the flops of all launches over the time at least one of them was running, and `concurrency` says how many were.
+            busy, cur_s, cur_e = 0.0, None, None
+            for s0, e, _ in sorted(gemm_iv):
+                if cur_e is None or s0 > cur_e:
+                    busy += (cur_e - cur_s) if cur_e is not None else 0.0
+                    cur_s, cur_e = s0, e
+                else:
+                    cur_e = max(cur_e, e)
+            busy += (cur_e - cur_s) if cur_e is not None else 0.0
+            concurrency = sum(gemm_times) / busy if busy > 0 else 1.0
+            achieved = len(gemm_times) * 2.0 * b ** 3 / (busy * 1e-3) / 1e12
             pmc = _profile_json("r06_gemm32_pmc.json") or {}
             line["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<float,128,128,32,true,true,false,0,2> (kernels.gemm on two fp32 tiles: "
                                                            "one 4096^3 product, 1024 workgroups; B tiles transposed once, then the N / T form)",
                                 "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "launches": len(gemm_times), "avg_ms": round(avg_ms, 4),
+                                "concurrency": round(concurrency, 3),
+                                "achieved_is": "flops of all launches / time at least one was running (HIP events on the launching streams, one clock); "
+                                               "avg_ms is a launch's own duration -- with `concurrency` launches sharing the chip",
                                 "algorithmic_flop_per_launch": 2 * b ** 3,
                                 "traffic": pmc.get("bytes_per_launch"),
                                 "traffic_unit": "B per 4096^3 product; from profiles/r06_gemm32_pmc.json (rocprofv3 --pmc, separate passes of "

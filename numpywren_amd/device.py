@@ -490,14 +490,25 @@ class HipBackend(object):
         # count > 1: one batched launch over `count` tiles -- reported as `count` entries of duration / count
         self.kernel_timers.setdefault(name if part is None else name + "@" + part, []).append((ev0, ev1, count))
 
-    def collect_kernel_times(self):
-        """{name: [milliseconds per launch]}; synchronises the device."""
+    def collect_kernel_times(self, intervals=False):
+        """{name: [milliseconds per launch]}; synchronises the device.  intervals=True: {name: [(start ms, end ms, count)]} on one
+        clock (the first bracket's opening event), for callers that launch the same kind on several streams at once and need to
+        know how many ran side by side."""
         self.synchronize()
         out = {}
+        ref = None
         for name, pairs in (self.kernel_timers or {}).items():
             out[name] = []
             for a, b, count in pairs:
-                out[name] += [self.elapsed_ms(a, b) / count] * count
+                if intervals:
+                    if ref is None:
+                        ref = a
+                    t0 = self.elapsed_ms(ref, a) if a is not ref else 0.0
+                    out[name].append((t0, t0 + self.elapsed_ms(a, b), count))
+                else:
+                    out[name] += [self.elapsed_ms(a, b) / count] * count
+        for name, pairs in (self.kernel_timers or {}).items():
+            for a, b, count in pairs:
                 self.recycle_event(a)
                 self.recycle_event(b)
         self.kernel_timers = None
