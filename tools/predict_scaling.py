@@ -49,7 +49,8 @@ TILE_BYTES = 4096 * 4096 * 8
 # batched QR of 4096^2 tiles, ms per call by batch size: dense leaves / stacked-triangle tree nodes, with T and R only
 GEQRT_MS = {True: {1: 18.4, 2: 21.5, 4: 27.1, 8: 36.4, 16: 60.0, 32: 105.0}, False: {1: 16.5, 2: 19.5, 4: 24.0, 8: 31.0, 16: 47.2, 32: 77.8}}
 TPQRT_MS = {True: {1: 18.8, 2: 20.5, 4: 25.6, 8: 35.1, 16: 52.7, 32: 87.9}, False: {1: 17.5, 2: 19.0, 4: 22.5, 8: 27.0, 16: 36.2, 32: 56.9}}
-SGEMM_TILE_MS = 2 * 4096 ** 3 / 131.5e12 * 1e3      # 32768^2 fp32 program at 131.5 TFLOP/s in the parity mode, adds included
+SGEMM_TILE_MS = 2 * 4096 ** 3 / 136.3e12 * 1e3      # 32768^2 fp32 program at 136.3 TFLOP/s in the parity mode, adds included (round 6: two
+                                                    # executor streams, the add tree beside the products; 131.5 with one stream until round 5)
 
 
 def batched_ms(table, count):
