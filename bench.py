@@ -523,7 +523,7 @@ def tsqr_roofline(times, b, r_only):
     t_hbm = bytes32 / (HBM_ACHIEVABLE_GBPS * 1e9) * 1e3 if bytes32 else None
     kernel = ("npw_dgeqrt_batched x32 (kernels.qr_factor on 32 leaves of 4096^2: panel chain + three levels of block reflectors; "
               "dominant device kernels by rocprof share: gemm_kernel<double,128,128,16,true,true,false,0,2> -- the rank-256 far update -- "
-              "and gemm_kernel<double,128,256,16,false,false,false,0,4> -- its X^T = W2^T V product; profiles/r06_qr_batched32*_kernel_stats.csv)")
+              "and gemm_kernel<double,128,256,16,false,false,false,4,4> -- its X^T = W2^T V product; profiles/r06_qr_batched32*_kernel_stats.csv)")
     mfma_view = {"achieved": round(tflops, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / FP64_MFMA_PEAK_TFLOPS, 4),
                  "bound_ms_per_batch_of_32": round(t_mfma, 2), "algorithmic_flop_per_tile": flop}
     common = {"kernel": kernel, "launches": len(leaf), "avg_ms": round(avg_ms, 4), "avg_ms_is": "per leaf tile (a call of 32 tiles / 32)",
