@@ -296,6 +296,15 @@ def _worker(rank, world, port, scenario, outdir):
         got = dist.gather_matrix(meta["outputs"][0], comm)
         if rank == 0:
             np.testing.assert_allclose(got, np.linalg.cholesky(A), rtol=1e-10, atol=1e-10)
+    elif scenario == "calib":
+        # the link calibration on more than two ranks of the (blocking) host transport: the shift exchanges at distance 1 and
+        # world - 1 are rings of blocking pairs that must not lock up; every rank ends with the same gathered table
+        calib = dist.link_calibration(comm, nbytes=1 << 14, repeats=1)
+        assert calib["transport"] == "host" and len(calib["samples"]) == 2 * world
+        assert {(s_["rank"], s_["d"]) for s_ in calib["samples"]} == {(r, d) for r in range(world) for d in (1, world - 1)}
+        tables = [None] * world
+        comm.dist.all_gather_object(tables, calib["xgmi_GBps"])
+        assert all(t == tables[0] for t in tables) and tables[0]["min"] > 0
     elif scenario == "not_pd":
         A = np.eye(32)
         A[20, 20] = -1.0
@@ -355,6 +364,10 @@ def test_time_limit_is_a_collective_decision(tmp_path):
 def test_a_stalled_rank_is_reported_by_the_ranks_it_holds_up(tmp_path):
     """the per-rank stall report (dist.StallWatch) and the link calibration's fields on two gloo ranks."""
     _spawn(2, "stalled_rank", tmp_path)
+
+
+def test_link_calibration_on_four_host_ranks(tmp_path):
+    _spawn(4, "calib", tmp_path)
 
 
 def test_failure_reaches_every_rank(tmp_path):
