@@ -761,6 +761,13 @@ def link_calibration(comm, nbytes=128 << 20, repeats=3):
             return tr.recv(rank, meta)
         return be.copy(src)
 
+    try:
+        return _link_calibration_body(comm, be, tr, rank, world, n, src, meta, rccl, watch, what, timed, shift, self_exchange, repeats)
+    finally:
+        watch.close()
+
+
+def _link_calibration_body(comm, be, tr, rank, world, n, src, meta, rccl, watch, what, timed, shift, self_exchange, repeats):
     samples = []
     if world == 1:
         what[0] = "self-exchange"
