@@ -821,7 +821,8 @@ def main():
         be.synchronize()
         elapsed, meta = run.timed(lambda: alg_wrappers.gemm(A, B), args.steps, args.warmup, timers=("gemm",))
         gemm_iv = be.collect_kernel_times(intervals=True).get("gemm", []) if comm is None else []
-        gemm_times = [e - s0 for s0, e, _ in gemm_iv]
+        gemm_times = [(e - s0) / max(1, c) for s0, e, c in gemm_iv]      # per product: a batched launch of c products / c
+        gemm_products = sum(max(1, c) for _, _, c in gemm_iv)
         run_step_ms = run.step_ms
         value = args.steps * 2.0 * n ** 3 / elapsed / 1e12
         line = {"metric": "achieved fp32 TFLOP/s, N x N GEMM program (2 N^3 / wall)", "value": round(value, 3),
@@ -844,13 +845,15 @@ def main():
                 else:
                     cur_e = max(cur_e, e)
             busy += (cur_e - cur_s) if cur_e is not None else 0.0
-            concurrency = sum(gemm_times) / busy if busy > 0 else 1.0
-            achieved = len(gemm_times) * 2.0 * b ** 3 / (busy * 1e-3) / 1e12
+            concurrency = sum(e - s0 for s0, e, _ in gemm_iv) / busy if busy > 0 else 1.0
+            achieved = gemm_products * 2.0 * b ** 3 / (busy * 1e-3) / 1e12
             pmc = _profile_json("r06_gemm32_pmc.json") or {}
             line["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<float,128,128,32,true,true,false,0,2> (kernels.gemm on two fp32 tiles: "
-                                                           "one 4096^3 product, 1024 workgroups; B tiles transposed once, then the N / T form)",
+                                                           "one 4096^3 product = 1024 workgroups; the executor hands the ready products over in "
+                                                           "launches of up to 16, npw_sgemm_batched; B tiles transposed once, then the N / T form)",
                                 "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "launches": len(gemm_times), "avg_ms": round(avg_ms, 4),
+                                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "launches": len(gemm_iv), "products": gemm_products, "avg_ms": round(avg_ms, 4),
+                                "avg_ms_is": "per 4096^3 product (a launch's duration / the products it holds)",
                                 "concurrency": round(concurrency, 3),
                                 "achieved_is": "flops of all launches / time at least one was running (HIP events on the launching streams, one clock); "
                                                "avg_ms is a launch's own duration -- with `concurrency` launches sharing the chip",

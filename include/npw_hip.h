@@ -132,6 +132,16 @@ int npw_dgemm(char transA, char transB, int64_t m, int64_t n, int64_t k, double 
               const double* A, int64_t lda, const double* B, int64_t ldb, double beta,
               const double* C, int64_t ldc, double* D, int64_t ldd, const int32_t* skip_flag,
               npw_stream_t stream);
+/* `count` (<= 16) independent products D[z] = op(A[z]) * op(B[z]) of ONE shape, transposition and leading dimensions as ONE
+ * launch (blockIdx.z = problem): the ready `gemm` tasks of the GEMM program (reference algs.py:251-266: M N K independent
+ * starters, one RemoteCall of kernels.gemm each, lambdapack.py:360-380) handed over together by the executor -- workgroups
+ * flow from one problem's tiles into the next one's, the chip drains once per batch instead of once per product.  Arrays of
+ * `count` device pointers; every tile 16-byte aligned.  Each problem is computed exactly as npw_dgemm / npw_sgemm computes it
+ * (same tiling, same order of products: the same bits). */
+int npw_dgemm_batched(int count, char transA, char transB, int64_t m, int64_t n, int64_t k, const double* const* A, int64_t lda,
+                      const double* const* B, int64_t ldb, double* const* D, int64_t ldd, npw_stream_t stream);
+int npw_sgemm_batched(int count, char transA, char transB, int64_t m, int64_t n, int64_t k, const float* const* A, int64_t lda,
+                      const float* const* B, int64_t ldb, float* const* D, int64_t ldd, npw_stream_t stream);
 /* fp32 flavour on v_mfma_f32_16x16x4_f32 (BASELINE config 5). */
 int npw_sgemm(char transA, char transB, int64_t m, int64_t n, int64_t k, float alpha,
               const float* A, int64_t lda, const float* B, int64_t ldb, float beta, const float* C,

@@ -68,6 +68,8 @@ PROTOTYPES = {
                           _i64, _vp, _vp]),
     "npw_dgemm_nt_sub_workspace_bytes": (c_size_t, [_i64, _i64, _i64]),
     "npw_dgemm_nt_sub": (c_int, [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "npw_dgemm_batched": (c_int, [c_int, ctypes.c_char, ctypes.c_char, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "npw_sgemm_batched": (c_int, [c_int, ctypes.c_char, ctypes.c_char, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "npw_dgemm_nt_sub_batched_workspace_bytes": (c_size_t, [c_int, _i64, _i64, _i64]),
     "npw_dgemm_nt_sub_batched": (c_int, [c_int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "npw_dtrsm_rltn_workspace_bytes": (_sz, [_i64, _i64]),

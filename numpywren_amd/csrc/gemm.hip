@@ -929,6 +929,35 @@ template int gemm<float>(char, char, int64_t, int64_t, int64_t, float, const flo
 
 }  // namespace npw
 
+namespace {
+template <typename T>
+int gemm_batched_impl(const char* who, int count, char transA, char transB, int64_t m, int64_t n, int64_t k, const T* const* A,
+                      int64_t lda, const T* const* B, int64_t ldb, T* const* D, int64_t ldd, npw_stream_t stream) {
+    NPW_REQUIRE(count >= 0 && m >= 0 && n >= 0 && k >= 0, "%s: negative argument", who);
+    if (count == 0 || m == 0 || n == 0) return NPW_OK;
+    NPW_REQUIRE(count <= 16, "%s: at most 16 problems per call", who);
+    NPW_REQUIRE(A && B && D, "%s: NULL argument", who);
+    int64_t da[16], db[16], dd[16];
+    for (int z = 0; z < count; ++z) {
+        NPW_REQUIRE(A[z] && B[z] && D[z], "%s: NULL tile (problem %d)", who, z);
+        NPW_REQUIRE(((reinterpret_cast<uintptr_t>(A[z]) | reinterpret_cast<uintptr_t>(B[z]) | reinterpret_cast<uintptr_t>(D[z])) & 15) == 0,
+                    "%s: tiles must be 16-byte aligned", who);
+        da[z] = A[z] - A[0];
+        db[z] = B[z] - B[0];
+        dd[z] = D[z] - D[0];
+    }
+    npw::GemmOpts o;
+    if (count > 1) {
+        o.batch = count;
+        o.delta_a = da;
+        o.delta_b = db;
+        o.delta_d = dd;
+    }
+    return npw::gemm<T>(transA, transB, m, n, k, T(1), A[0], lda, B[0], ldb, T(0), nullptr, 0, D[0], ldd, o, npw::as_stream(stream));
+}
+
+}  // namespace
+
 extern "C" {
 
 int npw_dgemm(char transA, char transB, int64_t m, int64_t n, int64_t k, double alpha,
@@ -1054,6 +1083,16 @@ int npw_dgemm_nt_sub(int64_t m, int64_t n, int64_t k, const double* S, int64_t l
 // npw_dgemm_nt_sub computes it (same tiles, same order of products).  When EVERY problem has X[z] == Y[z] (and the
 // symmetric route's shape) the batch takes that route: one launch over all problems' strictly-lower tile pairs, then
 // the diagonal blocks problem by problem (workspace: npw_dgemm_nt_sub_workspace_bytes(m, n, k), may be NULL).
+int npw_dgemm_batched(int count, char transA, char transB, int64_t m, int64_t n, int64_t k, const double* const* A, int64_t lda,
+                      const double* const* B, int64_t ldb, double* const* D, int64_t ldd, npw_stream_t stream) {
+    return gemm_batched_impl<double>("npw_dgemm_batched", count, transA, transB, m, n, k, A, lda, B, ldb, D, ldd, stream);
+}
+
+int npw_sgemm_batched(int count, char transA, char transB, int64_t m, int64_t n, int64_t k, const float* const* A, int64_t lda,
+                      const float* const* B, int64_t ldb, float* const* D, int64_t ldd, npw_stream_t stream) {
+    return gemm_batched_impl<float>("npw_sgemm_batched", count, transA, transB, m, n, k, A, lda, B, ldb, D, ldd, stream);
+}
+
 size_t npw_dgemm_nt_sub_batched_workspace_bytes(int count, int64_t m, int64_t n, int64_t k) {
     return count <= 0 ? 0 : (size_t)count * npw_dgemm_nt_sub_workspace_bytes(m, n, k);
 }

@@ -632,7 +632,10 @@ class LambdaPackExecutor(object):
         """The batched implementation of the task's kernel, or None (no batching configured / kernel has none)."""
         if self.batch_tasks <= 1 or self.program.block_sparse:
             return None
-        return getattr(self.compiled.kernel(expr_idx), "_npw_batch", None)
+        kernel = self.compiled.kernel(expr_idx)
+        if self.fusion is not None and getattr(kernel, "__name__", "") == "gemm":
+            return None      # fused GEMM reduction: every product goes through ReductionFusion.run, one by one
+        return getattr(kernel, "_npw_batch", None)
 
     def run_batch(self, nodes, stream=None):
         """Run the ready tasks `nodes` (all of the same expr_idx, whose kernel has a `_npw_batch`) with one call.

@@ -109,6 +109,29 @@ def _gemm_flops(A, B):
 gemm.flops = _gemm_flops
 
 
+def _gemm_batch(be, stream, arg_lists, kwargs_list):
+    """Ready gemm tasks of one statement (the M N K starters of the GEMM program, Temp[i, j, k, 0] = gemm(A[i, k], B[k, j]),
+    reference algs.py:253-256) as batched launches of up to 16 products (HipBackend.gemm_batched): tasks with two device tiles
+    and the same transpose kwargs together, anything else one by one.  Same outputs as `gemm` for each task."""
+    out = [None] * len(arg_lists)
+    groups = {}
+    for pos, (args, kw) in enumerate(zip(arg_lists, kwargs_list)):
+        plain = (len(args) == 2 and all(isinstance(a, DeviceTile) and a.ndim == 2 for a in args) and
+                 set(kw) <= {"transpose_A", "transpose_B"})
+        if plain:
+            groups.setdefault((bool(kw.get("transpose_A", False)), bool(kw.get("transpose_B", False))), []).append(pos)
+        else:
+            out[pos] = _gemm(*args, **kw)
+    for (ta, tb), members in groups.items():
+        res = be.gemm_batched([tuple(arg_lists[p]) for p in members], ta, tb, stream)
+        for p, r in zip(members, res):
+            out[p] = r
+    return out
+
+
+gemm._npw_batch = _gemm_batch
+
+
 @_kernel
 def _syrk(be, stream, s, x, y, *args, **kwargs):
     """s - x . y^T; returns s itself when x or y is allclose to 0 (reference kernels.py:212-215)."""

@@ -150,6 +150,10 @@ class OracleBackend(object):
             return out
         return HostTile(r)
 
+    def gemm_batched(self, problems, transpose_A=False, transpose_B=False, stream=None):
+        self.calls.append(("gemm_batched", len(problems)))
+        return [self.gemm(A, B, transpose_A, transpose_B, stream) for A, B in problems]
+
     def syrk(self, S, X, Y, stream=None, inplace=False, exact_zero=True):
         self.calls.append(("syrk", stream))
         if exact_zero:

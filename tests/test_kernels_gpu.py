@@ -199,6 +199,30 @@ def test_add_matrices_promotes_to_float64():
     assert np.array_equal(kernels.add_matrices(*many), oracle.add_matrices(*many))
 
 
+@pytest.mark.parametrize("dtype,ta,tb", [(np.float64, False, False), (np.float64, False, True), (np.float64, True, False),
+                                         (np.float32, False, False), (np.float32, True, True)])
+def test_gemm_batched_is_gemm_bit_for_bit(dtype, ta, tb):
+    """npw_dgemm_batched / npw_sgemm_batched (the executor's batch of ready gemm tasks): every problem of the one launch equals
+    the single call bitwise -- full tiles, a ragged shape (EDGE tiling), 1, 2, 5 and 19 problems (two launches)."""
+    from numpywren_amd.device import get_backend
+    be = get_backend()
+    rng = np.random.default_rng(71)
+    for (m, n, k), count in (((256, 128, 192), 5), ((200, 67, 93), 2), ((128, 128, 64), 19), ((64, 64, 64), 1)):
+        As = [rng.standard_normal((k, m) if ta else (m, k)).astype(dtype) for _ in range(count)]
+        Bs = [rng.standard_normal((n, k) if tb else (k, n)).astype(dtype) for _ in range(count)]
+        dA, dB = [be.to_device(a) for a in As], [be.to_device(b) for b in Bs]
+        got = be.gemm_batched(list(zip(dA, dB)), ta, tb)
+        for a, b, da, db, g in zip(As, Bs, dA, dB, got):
+            one = be.to_host(be.gemm(da, db, ta, tb))
+            assert g.dtype == dtype and np.array_equal(be.to_host(g), one)
+            ref = oracle.gemm(a.astype(np.float64), b.astype(np.float64), transpose_A=ta, transpose_B=tb)
+            np.testing.assert_allclose(one, ref, rtol=0, atol=(1e-12 if dtype == np.float64 else 1e-4) * k)
+    # through kernels.gemm's batch entry (what the executor calls), mixed with a host-array task
+    a, b = rng.standard_normal((64, 32)), rng.standard_normal((32, 48))
+    outs = kernels.gemm._npw_batch(be, None, [[be.to_device(a), be.to_device(b)], [be.to_device(a), be.to_device(b)], [a, b]], [{}, {}, {}])
+    assert np.array_equal(be.to_host(outs[0]), be.to_host(outs[1])) and np.allclose(outs[2], a @ b)
+
+
 def test_add_matrices_skips_the_shared_zero_tile_bit_for_bit():
     """The padding operands of the GEMM program's add tree are reads of never-written constant_zeros tiles: the backend's shared
     zero tile, which add_n does not read.  Same bits as the reference's np.zeros(shape) += a, signed zeros included."""
